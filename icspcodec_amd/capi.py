@@ -1,0 +1,186 @@
+"""ctypes binding of the C ABI in include/icsp_hip.h (icspcodec_amd/libicsp_hip.so).
+
+This is the host-side mirror used by tests and bench.py; the production host is the C++ program
+icspcodec_amd/csrc/icsp_enc_main.cpp which links the same library.  There is no CPU fallback: if the HIP library
+is missing or no device is usable, construction raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libicsp_hip.so")
+
+# every symbol include/icsp_hip.h declares
+SYMBOLS = [
+    "icsp_create", "icsp_destroy", "icsp_strerror", "icsp_last_error", "icsp_encode_gop", "icsp_upload",
+    "icsp_encode_resident", "icsp_sync", "icsp_download", "icsp_device_view", "icsp_download_debug",
+    "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
+    "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream",
+]
+KERNELS = ["k_intra_luma", "k_block_sums", "k_dc_chain", "k_residual", "k_me_sad", "k_me_resolve"]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("qp_dc", C.c_int), ("qp_ac", C.c_int), ("intra_period", C.c_int)]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [("frames", C.c_void_p), ("levels", C.c_void_p), ("acflag", C.c_void_p), ("mpm_mode", C.c_void_p),
+                ("mvd", C.c_void_p), ("recon", C.c_void_p), ("stream", C.c_void_p), ("max_frames", C.c_int), ("n_mb", C.c_int)]
+
+
+class IcspError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libicsp_hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IcspError(f"{LIB_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+        lib = C.CDLL(LIB_PATH)
+        lib.icsp_strerror.restype = C.c_char_p
+        lib.icsp_last_error.restype = C.c_char_p
+        lib.icsp_last_error.argtypes = [C.c_void_p]
+        lib.icsp_kernel_name.restype = C.c_char_p
+        lib.icsp_bitstream_bound.restype = C.c_size_t
+        lib.icsp_bitstream_bound.argtypes = [C.POINTER(Params), C.c_int]
+        vp = C.c_void_p
+        lib.icsp_create.argtypes = [C.POINTER(vp), C.POINTER(Params), C.c_int, C.c_int]
+        lib.icsp_destroy.argtypes = [vp]
+        lib.icsp_encode_gop.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
+        lib.icsp_upload.argtypes = [vp, vp, C.c_int, C.c_int]
+        lib.icsp_encode_resident.argtypes = [vp, C.c_int, C.c_int]
+        lib.icsp_sync.argtypes = [vp]
+        lib.icsp_download.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+        lib.icsp_device_view.argtypes = [vp, C.POINTER(DeviceView)]
+        lib.icsp_download_debug.argtypes = [vp, C.c_int, C.c_int, vp, vp]
+        lib.icsp_debug_keep_coef.argtypes = [vp, C.c_int]
+        lib.icsp_download_coef.argtypes = [vp, C.c_int, C.c_int, vp]
+        lib.icsp_profile_enable.argtypes = [vp, C.c_int]
+        lib.icsp_profile_reset.argtypes = [vp]
+        lib.icsp_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+        lib.icsp_write_bitstream.argtypes = [C.POINTER(Params), C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        _lib = lib
+    return _lib
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def write_bitstream(width, height, qp_dc, qp_ac, intra_period, levels, acflag, mpm, mvd) -> bytes:
+    """Host back end: the reference's makebitstream (ENC:4849-6334) on the encoder outputs.  Needs no GPU."""
+    lib = load()
+    p = Params(width, height, qp_dc, qp_ac, intra_period)
+    lv = np.ascontiguousarray(levels, np.int16); ac = np.ascontiguousarray(acflag, np.uint8)
+    mp = np.ascontiguousarray(mpm, np.uint8); mv = np.ascontiguousarray(mvd, np.int8)
+    n = lv.shape[0]
+    cap = lib.icsp_bitstream_bound(C.byref(p), n)
+    out = np.zeros(cap, np.uint8)
+    nbytes = C.c_size_t(0)
+    rc = lib.icsp_write_bitstream(C.byref(p), n, _vp(lv), _vp(ac), _vp(mp), _vp(mv), _vp(out), cap, C.byref(nbytes))
+    if rc:
+        raise IcspError(lib.icsp_strerror(rc).decode())
+    return out[: nbytes.value].tobytes()
+
+
+class Encoder:
+    """One context on one device (icsp_create ... icsp_destroy)."""
+
+    def __init__(self, width=352, height=288, qp_dc=16, qp_ac=16, intra_period=0, device=0, max_frames=300):
+        self.lib = load()
+        self.params = Params(width, height, qp_dc, qp_ac, intra_period)
+        self.width, self.height = width, height
+        self.nmb = (width // 16) * (height // 16)
+        self.fsz = width * height * 3 // 2
+        self.max_frames = max_frames
+        self.ctx = C.c_void_p()
+        rc = self.lib.icsp_create(C.byref(self.ctx), C.byref(self.params), device, max_frames)
+        if rc:
+            raise IcspError(f"icsp_create: {self.lib.icsp_strerror(rc).decode()}")
+
+    def _chk(self, rc, what):
+        if rc:
+            raise IcspError(f"{what}: {self.lib.icsp_strerror(rc).decode()} [{self.lib.icsp_last_error(self.ctx).decode()}]")
+
+    def close(self):
+        if self.ctx:
+            self.lib.icsp_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _alloc(self, n):
+        return dict(levels=np.zeros((n, self.nmb, 6, 64), np.int16), acflag=np.zeros((n, self.nmb, 6), np.uint8),
+                    mpm=np.zeros((n, self.nmb, 4), np.uint8), mvd=np.zeros((n, self.nmb, 2), np.int8),
+                    recon=np.zeros((n, self.fsz), np.uint8))
+
+    def encode(self, yuv: np.ndarray) -> dict:
+        """icsp_encode_gop: host frames in, host results out."""
+        y = np.ascontiguousarray(yuv, np.uint8).reshape(-1, self.fsz)
+        n = y.shape[0]
+        o = self._alloc(n)
+        self._chk(self.lib.icsp_encode_gop(self.ctx, _vp(y), n, _vp(o["levels"]), _vp(o["acflag"]), _vp(o["mpm"]),
+                                           _vp(o["mvd"]), _vp(o["recon"])), "icsp_encode_gop")
+        return o
+
+    def upload(self, yuv: np.ndarray, first=0):
+        y = np.ascontiguousarray(yuv, np.uint8).reshape(-1, self.fsz)
+        self._chk(self.lib.icsp_upload(self.ctx, _vp(y), first, y.shape[0]), "icsp_upload")
+        self._chk(self.lib.icsp_sync(self.ctx), "icsp_sync")
+        return y.shape[0]
+
+    def encode_resident(self, first, n):
+        self._chk(self.lib.icsp_encode_resident(self.ctx, first, n), "icsp_encode_resident")
+
+    def sync(self):
+        self._chk(self.lib.icsp_sync(self.ctx), "icsp_sync")
+
+    def download(self, first, n, what=("levels", "acflag", "mpm", "mvd", "recon")) -> dict:
+        o = self._alloc(n)
+        args = [_vp(o[k]) if k in what else None for k in ("levels", "acflag", "mpm", "mvd", "recon")]
+        self._chk(self.lib.icsp_download(self.ctx, first, n, *args), "icsp_download")
+        return {k: o[k] for k in what}
+
+    def download_debug(self, first, n):
+        mv = np.zeros((n, self.nmb, 2), np.int8); mode = np.zeros((n, self.nmb, 4), np.uint8)
+        self._chk(self.lib.icsp_download_debug(self.ctx, first, n, _vp(mv), _vp(mode)), "icsp_download_debug")
+        return mv, mode
+
+    def keep_coef(self, on=True):
+        self._chk(self.lib.icsp_debug_keep_coef(self.ctx, int(on)), "icsp_debug_keep_coef")
+
+    def download_coef(self, first, n):
+        c = np.zeros((n, self.nmb, 6, 64), np.float64)
+        self._chk(self.lib.icsp_download_coef(self.ctx, first, n, _vp(c)), "icsp_download_coef")
+        return c
+
+    def device_view(self) -> DeviceView:
+        v = DeviceView()
+        self._chk(self.lib.icsp_device_view(self.ctx, C.byref(v)), "icsp_device_view")
+        return v
+
+    def profile(self, on=True):
+        self._chk(self.lib.icsp_profile_enable(self.ctx, int(on)), "icsp_profile_enable")
+        self._chk(self.lib.icsp_profile_reset(self.ctx), "icsp_profile_reset")
+
+    def profile_get(self) -> dict:
+        out = {}
+        for i, name in enumerate(KERNELS):
+            ms = C.c_double(0); n = C.c_longlong(0)
+            self._chk(self.lib.icsp_profile_get(self.ctx, i, C.byref(ms), C.byref(n)), "icsp_profile_get")
+            out[name] = (ms.value, n.value)
+        return out

@@ -1,0 +1,128 @@
+// icsp_bitstream.cpp — host back end of the C ABI: header + per-macroblock syntax + the 13-category code + MSB-first
+// bit packing, byte-exact to the reference's makebitstream (ENC:4849-4900), headerinit (ENC:4901-4922), allintraBody
+// (ENC:4923-5031), intraBody (ENC:5032-5131), interBody (ENC:5132-5236), DCentropy/ACentropy/MVentropy
+// (ENC:5417-5602, 5791-5989, 5990-6334).  ENC = /root/reference/source/encoder/ICSP_Codec_Encoder_source.cpp.
+//
+// Entropy coding is bit-serial and stays on the host (BASELINE.json north_star).  Differences from the reference, on
+// purpose: 64-bit bit counters and a caller-sized buffer (the reference's `int` counters overflow beyond 256 MiB and
+// its buffer is sized at 8 bits per luma pixel, ENC:4873-4875); the buffer is zero-initialised, which is what the
+// reference's malloc returns in practice (fresh mmap) and what its final partial byte relies on.
+#include <stdint.h>
+#include <string.h>
+#include "icsp_hip.h"
+
+namespace {
+
+struct BitWriter {
+    uint8_t* buf; size_t cap; size_t nbits; bool overflow;
+    // (buf[cnt++/8] <<= 1) |= bit  (ENC:4956): bits enter each byte MSB first; a final partial byte keeps its bits
+    // right-aligned, exactly as the reference leaves it.
+    inline void put(uint32_t value, int n)
+    {
+        for (int i = n - 1; i >= 0; i--) {
+            size_t byte = nbits >> 3;
+            if (byte >= cap) { overflow = true; return; }
+            buf[byte] = (uint8_t)((buf[byte] << 1) | ((value >> i) & 1u));
+            nbits++;
+        }
+    }
+};
+
+// One value of the shared DC / AC / MV code table (ENC:5417-5602): returns (code, length).
+inline void code_value(int v, uint32_t& code, int& len)
+{
+    const uint32_t s = (v >= 0) ? 1u : 0u;
+    uint32_t a = (uint32_t)(v >= 0 ? v : -v);
+    if (a == 0) { code = 0; len = 2; return; }                       // 00
+    if (a == 1) { code = (0x2u << 1) | s; len = 4; return; }          // 010 s
+    if (a <= 31) {                                                   // 011/100/101/110, s, e bits of a-2^e
+        int e = (a <= 3) ? 1 : (a <= 7) ? 2 : (a <= 15) ? 3 : 4;
+        uint32_t prefix = 2u + (uint32_t)e;                          // 3,4,5,6 = 011,100,101,110
+        code = (((prefix << 1) | s) << e) | (a - (1u << e));
+        len = 4 + e;
+        return;
+    }
+    int e = 5;
+    while (e < 11 && a >= (2u << e)) e++;                            // 2^e <= a < 2^(e+1), capped at e = 11 (a >= 2048)
+    uint32_t ones = (1u << (e - 2)) - 1u;                            // (e-2) one bits, then 0, then s
+    uint32_t c = (a - (1u << e)) & ((1u << e) - 1u);                 // the reference emits the low e bits only
+    code = (((ones << 1) << 1 | s) << e) | c;
+    len = (e - 2) + 2 + e;
+}
+
+inline void put_value(BitWriter& w, int v)
+{
+    uint32_t c; int n;
+    code_value(v, c, n);
+    w.put(c, n);
+}
+
+// DC code, ACflag, then either 63 literal zero bits or the 63 AC codes (ENC:4958-4977)
+inline void put_block(BitWriter& w, const int16_t* lv, int acflag)
+{
+    put_value(w, lv[0]);
+    w.put((uint32_t)acflag & 1u, 1);
+    if (acflag == 1) { w.put(0, 31); w.put(0, 32); }
+    else for (int i = 1; i < 64; i++) put_value(w, lv[i]);
+}
+
+} // namespace
+
+extern "C" {
+
+size_t icsp_bitstream_bound(const icsp_params_t* p, int n)
+{
+    if (!p || n < 0) return 0;
+    const size_t nmb = (size_t)(p->width / 16) * (p->height / 16);
+    // per macroblock at most 1 + 2*22 (mv) + 4*2 (mode bits) + 6*(22 + 1 + 63*22) bits
+    const size_t bits_per_mb = 1 + 44 + 8 + 6 * (22 + 1 + 63 * 22);
+    return 14 + ((size_t)n * nmb * bits_per_mb) / 8 + 2;
+}
+
+int icsp_write_bitstream(const icsp_params_t* p, int n, const int16_t* levels, const uint8_t* acflag,
+                         const uint8_t* mpm_mode, const int8_t* mvd, uint8_t* out, size_t cap, size_t* out_bytes)
+{
+    if (!p || !levels || !acflag || !mpm_mode || !mvd || !out || !out_bytes) return ICSP_ERR_UNENOUGH_PARAM;
+    if (cap < 15 || n < 0) return ICSP_ERR_UNCORRECT_PARAM;
+    memset(out, 0, cap);
+    // header: packed struct of 14 bytes (ICSP_Codec_Encoder.h:201-212), little-endian shorts
+    out[0] = 0; out[1] = 73; out[2] = 67; out[3] = 83; out[4] = 80;       // "\0ICSP" (ENC:4903)
+    const uint16_t hh = (uint16_t)p->height, ww = (uint16_t)p->width;
+    out[5] = (uint8_t)(hh & 0xff); out[6] = (uint8_t)(hh >> 8);
+    out[7] = (uint8_t)(ww & 0xff); out[8] = (uint8_t)(ww >> 8);
+    out[9] = (uint8_t)p->qp_dc; out[10] = (uint8_t)p->qp_ac; out[11] = 0;
+    const uint16_t outro = (uint16_t)((p->intra_period & 0x3f) << 7);       // 6 bits of intraPeriod, then 7 zero bits (ENC:4910-4921)
+    out[12] = (uint8_t)(outro & 0xff); out[13] = (uint8_t)(outro >> 8);
+
+    BitWriter w{ out + 14, cap - 14, 0, false };
+    const size_t nmb = (size_t)(p->width / 16) * (p->height / 16);
+    for (int f = 0; f < n; f++) {
+        const bool intra = (p->intra_period == 0) || (f % p->intra_period == 0);   // ENC:219, 4884
+        for (size_t mb = 0; mb < nmb; mb++) {
+            const size_t o = (size_t)f * nmb + mb;
+            const int16_t* lv = levels + o * 384;
+            const uint8_t* ac = acflag + o * 6;
+            if (intra) {
+                for (int k = 0; k < 4; k++) {                          // ENC:5052-5080
+                    w.put(mpm_mode[o * 4 + k] & 1u, 1);               // MPMFlag
+                    w.put((mpm_mode[o * 4 + k] >> 1) & 1u, 1);        // intraPredMode
+                    put_block(w, lv + k * 64, ac[k]);
+                }
+            } else {
+                w.put(1, 1);                                           // mv mode flag (ENC:5152)
+                put_value(w, mvd[o * 2]);                              // differential mv x then y (ENC:5154-5157)
+                put_value(w, mvd[o * 2 + 1]);
+                for (int k = 0; k < 4; k++) put_block(w, lv + k * 64, ac[k]);
+            }
+            put_block(w, lv + 4 * 64, ac[4]);                          // Cb, Cr (ENC:5088-5128, 5195-5234)
+            put_block(w, lv + 5 * 64, ac[5]);
+            if (w.overflow) return ICSP_ERR_RANGE;
+        }
+    }
+    const size_t body = w.nbits / 8 + 1;                               // fwrite(..., cntbits/8 + 1, ...) (ENC:4895, 5029)
+    if (body > cap - 14) return ICSP_ERR_RANGE;
+    *out_bytes = 14 + body;
+    return ICSP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,116 @@
+/*
+ * icsp_hip.h — C ABI of the MI355X (gfx950) implementation of ICSPCodec's per-macroblock encode loop.
+ *
+ * The reference has no plugin/FFI interface; its de-facto boundary is the three frame functions the
+ * scheduler calls:
+ *     int  allintraPrediction(FrameData*, int nframes, int QstepDC, int QstepAC);  ICSP_Codec_Encoder.h:250, caller ENC:221
+ *     void intraPrediction   (FrameData&,              int QstepDC, int QstepAC);  ICSP_Codec_Encoder.h:249, callers ENC:233, 202
+ *     int  interPrediction   (FrameData& cur, FrameData& prev, int, int);          ICSP_Codec_Encoder.h:265, callers ENC:238, 207
+ * plus, downstream, makebitstream (ICSP_Codec_Encoder.h:310, callers ENC:222, 242).
+ * (ENC = /root/reference/source/encoder/ICSP_Codec_Encoder_source.cpp.)
+ *
+ * This library replaces them with plain-pointer entry points over flat planes.  Data that crosses:
+ *   frames    uint8  [n][W*H*3/2]       planar I420 (Y, Cb, Cr) — the order YCbCrLoad reads (ENC:274-279)
+ *   levels    int16  [n][nMB][6][64]    zig-zag order (ENC:3031-3094); blocks 0-3 Y (raster in the MB), 4 Cb, 5 Cr
+ *                                        = intraReorderedblck8 / interReorderedblck8 / (intra|inter)Reorderedblck
+ *   acflag    uint8  [n][nMB][6]        1 = all 63 AC levels are zero (intraACflag / interACflag, ENC:2784-2792)
+ *   mpm_mode  uint8  [n][nMB][4]        bit0 MPMFlag, bit1 intraPredMode (I frames; 0 on P frames) (ENC:987-997)
+ *   mvd       int8   [n][nMB][2]        differential motion vector x,y = bd.mv after mvPrediction (ENC:2353; 0 on I frames)
+ *   recon     uint8  [n][W*H*3/2]       reconstructedY/Cb/Cr — what checkResultFrames dumps to test_yuv.yuv (ENC:6408-6410)
+ * nMB = (W/16)*(H/16), macroblocks in raster order.  W, H multiples of 16, 32 <= W <= 4096, 16 <= H <= 2304.
+ *
+ * Errors: every function returns 0 (= reference SUCCESS, ICSP_Codec_Encoder.h:33-39) or a positive
+ * icsp_status code; nothing calls exit().  There is NO CPU fallback: without a usable HIP device
+ * icsp_create fails with ICSP_ERR_NO_DEVICE.
+ * Threading: one context per device; calls on one context must be serialised by the caller; distinct
+ * contexts are independent (the host GOP dispatcher uses one thread per GPU, the analogue of
+ * encoding_thread, ENC:186-213).
+ */
+#ifndef ICSP_HIP_H
+#define ICSP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ICSP_OK = 0,                 /* SUCCESS          (ICSP_Codec_Encoder.h:35) */
+    ICSP_ERR_UNENOUGH_PARAM = 1, /* UNENOUGH_PARAM   (ICSP_Codec_Encoder.h:36) */
+    ICSP_ERR_UNCORRECT_PARAM = 2,/* UNCORRECT_PARAM  (ICSP_Codec_Encoder.h:37) */
+    ICSP_ERR_MEM_ALLOC = 3,      /* FAIL_MEM_ALLOC   (ICSP_Codec_Encoder.h:38) */
+    ICSP_ERR_NO_DEVICE = 4,      /* no HIP device / runtime unusable */
+    ICSP_ERR_HIP = 5,            /* a HIP call failed; see icsp_last_error() */
+    ICSP_ERR_RANGE = 6           /* frame range outside the context's capacity / not GOP aligned */
+} icsp_status;
+
+typedef struct {
+    int width, height;   /* luma size, multiples of 16 (the reference hard-codes 352x288, encoder_main.cpp:20) */
+    int qp_dc, qp_ac;    /* quantiser steps, > 0 (README: 1, 8 or 16) */
+    int intra_period;    /* 0 = every frame is an I frame (ALL_INTRA, ICSP_Codec_Encoder.h:18); k>0: frame n is I iff n%k==0 */
+} icsp_params_t;
+
+typedef struct icsp_ctx icsp_ctx_t; /* opaque: device buffers, stream and scratch for ONE device */
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+/* max_frames = capacity of the resident frame store (inputs + all outputs stay in HBM). */
+int icsp_create(icsp_ctx_t** out, const icsp_params_t* params, int device_id, int max_frames);
+int icsp_destroy(icsp_ctx_t* ctx);
+const char* icsp_strerror(int status);
+const char* icsp_last_error(const icsp_ctx_t* ctx);   /* text of the last HIP failure on this context */
+
+/* ---- one-call host path: replaces the allintraPrediction / intraPrediction+interPrediction loop of
+ *      single_thread_encoding (ENC:217-245) for frames [0, n).  Frame i is an I frame iff
+ *      intra_period == 0 or i % intra_period == 0; closed GOPs are encoded concurrently.
+ *      All pointers are caller-owned host memory; any output pointer may be NULL (skipped). ----- */
+int icsp_encode_gop(icsp_ctx_t* ctx, const uint8_t* yuv420_in, int n,
+                    int16_t* levels, uint8_t* acflag, uint8_t* mpm_mode, int8_t* mvd, uint8_t* recon);
+
+/* ---- resident path (inputs already in HBM when the timed region starts) --------------------- */
+int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv420_in, int first_frame, int n);   /* H2D into slots [first, first+n) */
+/* Encode slots [first, first+n); first must be GOP aligned (first % intra_period == 0).  Asynchronous
+ * on the context's stream. */
+int icsp_encode_resident(icsp_ctx_t* ctx, int first_frame, int n);
+int icsp_sync(icsp_ctx_t* ctx);
+int icsp_download(icsp_ctx_t* ctx, int first_frame, int n,
+                  int16_t* levels, uint8_t* acflag, uint8_t* mpm_mode, int8_t* mvd, uint8_t* recon);
+
+/* Device-side view for zero-copy users (bench.py fills `frames` from a torch tensor and reads the
+ * outputs in place).  Pointers are HBM addresses valid until icsp_destroy. */
+typedef struct {
+    void* frames; void* levels; void* acflag; void* mpm_mode; void* mvd; void* recon;
+    void* stream;         /* hipStream_t the kernels are launched on */
+    int max_frames, n_mb;
+} icsp_device_view_t;
+int icsp_device_view(icsp_ctx_t* ctx, icsp_device_view_t* out);
+
+/* ---- debug taps used by the parity tests (not part of the reference boundary) ---------------- */
+/* Raw motion vectors int8[n][nMB][2] (Reconstructedmv, ENC:2426) and chosen intra modes uint8[n][nMB][4]
+ * (DPCMmodePred, ENC:889...) of slots [first, first+n); either pointer may be NULL. */
+int icsp_download_debug(icsp_ctx_t* ctx, int first_frame, int n, int8_t* mv, uint8_t* intra_mode);
+/* When enabled (before encoding), forward-DCT coefficients before DC prediction/quantisation are kept:
+ * double[n][nMB][6][64], row-major [v][u] (DCT_block output, ENC:2685-2749).  Costs 8x the level store. */
+int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
+int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
+
+/* ---- per-kernel timing with HIP events on the launch stream ---------------------------------- */
+enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_BLOCK_SUMS, ICSP_K_DC_CHAIN, ICSP_K_RESIDUAL, ICSP_K_ME_SAD, ICSP_K_ME_RESOLVE, ICSP_K_COUNT };
+int icsp_profile_enable(icsp_ctx_t* ctx, int on);
+int icsp_profile_reset(icsp_ctx_t* ctx);
+/* Sums over launches since the last reset; syncs the stream. */
+int icsp_profile_get(icsp_ctx_t* ctx, int kernel, double* total_ms, long long* launches);
+const char* icsp_kernel_name(int kernel);
+
+/* ---- host back end: bit-exact restatement of makebitstream (ENC:4849-6334) -------------------- */
+/* Worst-case size in bytes of the .bin for n frames (header included). */
+size_t icsp_bitstream_bound(const icsp_params_t* params, int n);
+/* Packs header + body for frames [0, n) from the arrays above (host memory) into out (capacity cap).
+ * Writes the byte count to *out_bytes: 14 header bytes + cntbits/8 + 1 (ENC:4895, 5029). */
+int icsp_write_bitstream(const icsp_params_t* params, int n,
+                         const int16_t* levels, const uint8_t* acflag, const uint8_t* mpm_mode, const int8_t* mvd,
+                         uint8_t* out, size_t cap, size_t* out_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
