@@ -71,6 +71,7 @@ __constant__ MeTables c_me;
 struct Geo {
     int W, H, sw, sh, nmb, cols8, rows8, cw, ch;
     int qdc, qac;
+    uint32_t mdc, mac;                // ceil(2^32/q): |t|/q == umulhi(|t|, m) for |t| < 2^16, q > 1
     long long fsz;                    // bytes per frame = W*H*3/2
 };
 struct FrameSel { int first, stride, count; };     // item i -> frame slot first + i*stride
@@ -552,6 +553,8 @@ __global__ __launch_bounds__(64) void k_me_resolve(Geo g, FrameSel fs, DevBufs b
     }
 }
 
+#include "icsp_blk8.hip.inc"
+
 // ------------------------------------------------------------------------------------------------ host side
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return ICSP_ERR_HIP; } } while (0)
 
@@ -562,7 +565,7 @@ struct EvPair { hipEvent_t a, b; int kernel; };
 struct icsp_ctx {
     icsp_params_t p;
     Geo g;
-    int device, max_frames;
+    int device, max_frames, intra_waves;
     hipStream_t stream;
     DevBufs b;
     uint8_t* d_frames;
@@ -631,7 +634,20 @@ int check_range(icsp_ctx* ctx, int first, int n)
     return 0;
 }
 
-constexpr int kIntraWaves = 16;
+// waves per I-frame workgroup: enough for the widest step of the block wavefront (2 blocks per wave)
+int intra_waves_needed(const Geo& g)
+{
+    int widest = 0;
+    const int nsteps = g.cols8 + 2 * (g.rows8 - 1);
+    for (int t = 0; t < nsteps; t++) {
+        int r_lo = t - (g.cols8 - 1); r_lo = (r_lo <= 0) ? 0 : (r_lo + 1) >> 1;
+        int r_hi = (g.rows8 - 1 < (t >> 1)) ? g.rows8 - 1 : (t >> 1);
+        if (r_hi - r_lo + 1 > widest) widest = r_hi - r_lo + 1;
+    }
+    return (widest + 1) / 2;
+}
+
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st);
 
 int encode_range(icsp_ctx* ctx, int first, int n)
 {
@@ -646,11 +662,11 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // ---- step 0: the I frame of every GOP
     {
         FrameSel fs{ first, L, G };
-        launch_timed(ctx, ICSP_K_INTRA_LUMA, [&] { hipLaunchKernelGGL(k_intra_luma<kIntraWaves>, dim3(G), dim3(kIntraWaves * 64), 0, st, g, fs, b); });
+        launch_timed(ctx, ICSP_K_INTRA_LUMA, [&] { launch_intra_luma(ctx, g, fs, b, G, st); });
         const long long nblk = (long long)G * g.nmb * 2;
         launch_timed(ctx, ICSP_K_BLOCK_SUMS, [&] { hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, g, fs, b, 4, 2, 0); });
         launch_timed(ctx, ICSP_K_DC_CHAIN, [&] { hipLaunchKernelGGL(k_dc_chain, dim3(G, 2), dim3(64), 0, st, g, fs, b, 1); });
-        launch_timed(ctx, ICSP_K_RESIDUAL, [&] { hipLaunchKernelGGL(k_residual, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, g, fs, b, 4, 2, 0); });
+        launch_timed(ctx, ICSP_K_RESIDUAL, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, st, g, fs, b, 4, 2, 0); });
     }
     // ---- steps 1..L-1: the i-th P frame of every GOP that has one
     for (int i = 1; i < L; i++) {
@@ -663,10 +679,22 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         launch_timed(ctx, ICSP_K_ME_RESOLVE, [&] { hipLaunchKernelGGL(k_me_resolve, dim3(Gi), dim3(64), (size_t)g.nmb * 2, st, g, fs, b); });
         launch_timed(ctx, ICSP_K_BLOCK_SUMS, [&] { hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
         launch_timed(ctx, ICSP_K_DC_CHAIN, [&] { hipLaunchKernelGGL(k_dc_chain, dim3(Gi, 3), dim3(64), 0, st, g, fs, b, 0); });
-        launch_timed(ctx, ICSP_K_RESIDUAL, [&] { hipLaunchKernelGGL(k_residual, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
+        launch_timed(ctx, ICSP_K_RESIDUAL, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
     }
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
+{
+    // 32-lane form: two blocks per wave; enough waves for the widest step, capped at 16 (wider steps take rounds)
+    const int need = ctx->intra_waves;
+    if (need <= 2)       hipLaunchKernelGGL(k_intra_luma32<2>, dim3(G), dim3(128), 0, st, g, fs, b);
+    else if (need <= 4)  hipLaunchKernelGGL(k_intra_luma32<4>, dim3(G), dim3(256), 0, st, g, fs, b);
+    else if (need <= 6)  hipLaunchKernelGGL(k_intra_luma32<6>, dim3(G), dim3(384), 0, st, g, fs, b);
+    else if (need <= 8)  hipLaunchKernelGGL(k_intra_luma32<8>, dim3(G), dim3(512), 0, st, g, fs, b);
+    else if (need <= 11) hipLaunchKernelGGL(k_intra_luma32<11>, dim3(G), dim3(704), 0, st, g, fs, b);
+    else                 hipLaunchKernelGGL(k_intra_luma32<16>, dim3(G), dim3(1024), 0, st, g, fs, b);
 }
 
 } // namespace
@@ -714,7 +742,11 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     Geo& g = ctx->g;
     g.W = p->width; g.H = p->height; g.sw = g.W / 16; g.sh = g.H / 16; g.nmb = g.sw * g.sh;
     g.cols8 = 2 * g.sw; g.rows8 = 2 * g.sh; g.cw = g.W / 2; g.ch = g.H / 2;
-    g.qdc = p->qp_dc; g.qac = p->qp_ac; g.fsz = (long long)g.W * g.H * 3 / 2;
+    g.qdc = p->qp_dc; g.qac = p->qp_ac;
+    g.mdc = (uint32_t)((0x100000000ull + g.qdc - 1) / (unsigned)g.qdc);     // unused when q == 1 (would not fit 32 bits)
+    g.mac = (uint32_t)((0x100000000ull + g.qac - 1) / (unsigned)g.qac);
+    g.fsz = (long long)g.W * g.H * 3 / 2;
+    ctx->intra_waves = intra_waves_needed(g);
     memset(&ctx->b, 0, sizeof(ctx->b));
     ctx->stream = nullptr;
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
