@@ -1,0 +1,52 @@
+"""The C++ host program keeps the reference's command line (encoder_main.cpp, ICSP_Codec_Encoder_source.cpp:84-176)."""
+import hashlib
+import json
+import os
+import subprocess
+
+import pytest
+
+from icspcodec_amd import clipgen
+from oracle import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ENC = os.path.join(ROOT, "icspcodec_amd", "icsp_enc")
+
+
+def run(args, cwd):
+    return subprocess.run([ENC] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+def test_option_errors_match_reference_messages_and_exit_code(tmp_path):
+    cases = [([], b"[ERROR] unenough parameters in parsing_command\n"),
+             (["-i", "a_b.yuv", "-w", "352"], b"[ERROR] uncorrect parameters in parsing_command\n"),
+             (["--bogus", "1"], b"[ERROR] uncorrect parameters in parsing_command\n"),
+             (["-i", "missing_x.yuv", "-n", "1", "-q", "16"], b"fail to load cif.yuv\n error from YCbCrLoad\n")]
+    for args, msg in cases:
+        r = run(args, tmp_path)
+        assert r.returncode == 255 and r.stdout == msg, (args, r.stdout)
+        if os.path.exists(po.REF_ENC):          # where the real reference is built, it says the same
+            rr = subprocess.run([po.REF_ENC] + args, cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            assert rr.returncode == 255 and rr.stdout == msg, (args, rr.stdout)
+    r = run(["-h"], tmp_path)
+    assert r.returncode == 0 and r.stdout.startswith(b"usage: ./ICSPCodec [option] [values]\n")
+    r = run(["--help"], tmp_path)
+    assert r.returncode == 0 and b"--intraPeriod: period of intra frame(0: All intra)" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("period,extra", [(6, []), (0, []), (1, []), (6, ["--EnMultiThread", "1"])])
+def test_cli_outputs_equal_reference_files(tmp_path, golden_dir, period, extra):
+    n, qp = 12, 16
+    clip = clipgen.synth_clip("foremanlike", n)
+    fn = clipgen.file_name("foremanlike", n)
+    clip.tofile(tmp_path / fn)
+    r = run(["-i", fn, "-n", str(n), "-q", str(qp), "--intraPeriod", str(period)] + extra, tmp_path)
+    assert r.returncode == 0, r.stdout
+    lines = r.stdout.decode().splitlines()
+    assert lines == ["Encoding FRAME_%03d(%c) done!" % (f, "I" if period == 0 or f % period == 0 else "P") for f in range(n)]
+    streams = json.load(open(os.path.join(golden_dir, "streams.json")))
+    ref = [s for s in streams if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", n, qp, period) and "bin_sha256" in s][0]
+    binp = tmp_path / f"foremanlike_compCIF_{qp}_{qp}_{period}.bin"
+    assert hashlib.sha256(binp.read_bytes()).hexdigest() == ref["bin_sha256"]
+    assert hashlib.sha256((tmp_path / "test_yuv.yuv").read_bytes()).hexdigest() == ref["recon_sha256"]
