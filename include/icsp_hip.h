@@ -17,7 +17,7 @@
  *   mpm_mode  uint8  [n][nMB][4]        bit0 MPMFlag, bit1 intraPredMode (I frames; 0 on P frames) (ENC:987-997)
  *   mvd       int8   [n][nMB][2]        differential motion vector x,y = bd.mv after mvPrediction (ENC:2353; 0 on I frames)
  *   recon     uint8  [n][W*H*3/2]       reconstructedY/Cb/Cr — what checkResultFrames dumps to test_yuv.yuv (ENC:6408-6410)
- * nMB = (W/16)*(H/16), macroblocks in raster order.  W, H multiples of 16, 32 <= W <= 4096, 16 <= H <= 2304.
+ * nMB = (W/16)*(H/16) <= 16384, macroblocks in raster order.  W, H multiples of 16, 32 <= W <= 4096, 16 <= H <= 2304.
  *
  * Errors: every function returns 0 (= reference SUCCESS, ICSP_Codec_Encoder.h:33-39) or a positive
  * icsp_status code; nothing calls exit().  There is NO CPU fallback: without a usable HIP device
