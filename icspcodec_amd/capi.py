@@ -21,7 +21,7 @@ SYMBOLS = [
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream",
 ]
-KERNELS = ["k_intra_luma", "k_block_sums", "k_dc_chain", "k_residual", "k_me_sad", "k_me_resolve"]
+KERNELS = ["k_intra_luma", "k_block_sums", "k_dc_chain", "k_residual", "k_me", "k_frame_serial"]
 
 
 class Params(C.Structure):
@@ -173,8 +173,14 @@ class Encoder:
         self._chk(self.lib.icsp_device_view(self.ctx, C.byref(v)), "icsp_device_view")
         return v
 
-    def profile(self, on=True):
-        self._chk(self.lib.icsp_profile_enable(self.ctx, int(on)), "icsp_profile_enable")
+    def profile(self, on=True, only=None):
+        """on=True: HIP events around every kernel; only=[names]: just those kernels (cheaper inside a timed region)."""
+        flag = int(bool(on))
+        if on and only:
+            flag = 0
+            for name in only:
+                flag |= 1 << (KERNELS.index(name) + 1)
+        self._chk(self.lib.icsp_profile_enable(self.ctx, flag), "icsp_profile_enable")
         self._chk(self.lib.icsp_profile_reset(self.ctx), "icsp_profile_reset")
 
     def profile_get(self) -> dict:

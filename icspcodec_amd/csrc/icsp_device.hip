@@ -82,7 +82,9 @@ struct DevBufs {
     int16_t* levels; uint8_t* acflag; uint8_t* mpm; int8_t* mvd;
     int8_t* mv; uint8_t* imode;       // debug taps / inter-kernel data
     uint32_t* me_ent;                 // [slot][nmb][4] packed (mvx, mvy, next state)
-    int16_t* sums;                    // [slot][nmb][6] residual block sums
+    int16_t* sums;                    // [slot][nmb][6] residual block sums (I-frame chroma path)
+    int* me_flag;                     // [slot] set by k_me<false> when a macroblock of the frame broke out of its walk early
+    int16_t* me_sums;                 // [slot][nmb][4][6] residual block sums of a P-frame MB for each search state
     int16_t* dcpred;                  // [slot][nmb][6] DC predictors
     double* coef;                     // optional [slot][nmb][6][64]
 };
@@ -126,9 +128,11 @@ __device__ __forceinline__ int clip255(int t) { return min(max(t, 0), 255); }
 // replication, except that the last padded row and column are never written and stay 0.
 __device__ __forceinline__ int pad_fetch(const uint8_t* plane, int w, int h, int pad, int py, int px)
 {
-    if (py == h + 2 * pad - 1 || px == w + 2 * pad - 1) return 0;
-    int y = min(max(py - pad, 0), h - 1), x = min(max(px - pad, 0), w - 1);
-    return plane[y * w + x];
+    // branch-free: the clamped address is always valid, so the load is unconditional and several fetches can be in flight
+    const int y = min(max(py - pad, 0), h - 1), x = min(max(px - pad, 0), w - 1);
+    const int v = plane[y * w + x];
+    const bool zero = (py == h + 2 * pad - 1) | (px == w + 2 * pad - 1);
+    return zero ? 0 : v;
 }
 
 // Residual sample + prediction for the lane's pixel of block (slot, mb, k).  inter=false: chroma of an I frame
@@ -237,128 +241,7 @@ __global__ __launch_bounds__(256) void k_dc_chain(Geo g, FrameSel fs, DevBufs b,
     }
 }
 
-// ------------------------------------------------------------------------------------------------ motion search
-// One wave per macroblock.  The current block and its 48x48 search window (prediction of the reference's padded
-// image) are staged in LDS; the 129 distinct candidate offsets of the four search-direction states are evaluated
-// with v_sad_u8; then each state's 64-step walk is resolved with the reference's rules (first strict minimum wins;
-// a second zero-SAD candidate breaks the walk and wins, ENC:2130-2141).  Output: for each start state the motion
-// vector and the state the next macroblock starts in.
-constexpr int kWinStride = 52;   // bytes per LDS window row (48 + pad, 13 dwords: odd => rows spread over banks)
-__global__ __launch_bounds__(256) void k_me_sad(Geo g, FrameSel fs, DevBufs b)
-{
-    __shared__ uint32_t s_win[4][48 * kWinStride / 4];
-    __shared__ uint32_t s_cur[4][64];
-    __shared__ int s_sad[4][132];
-    const int wave = threadIdx.x >> 6, l = lane_id();
-    const long long id = (long long)blockIdx.x * 4 + wave;
-    if (id >= (long long)fs.count * g.nmb) return;
-    const int mb = (int)(id % g.nmb);
-    const int slot = fs.first + (int)(id / g.nmb) * fs.stride;
-    const int R = mb / g.sw, C = mb % g.sw;
-    const uint8_t* Y = b.frames + slot * g.fsz;
-    const uint8_t* P = b.recon + (slot - 1) * g.fsz;
-    uint32_t* win = s_win[wave];
-    uint32_t* curl = s_cur[wave];
-    // current block: 64 dwords
-    curl[l] = *(const uint32_t*)(Y + (R * 16 + (l >> 2)) * g.W + C * 16 + (l & 3) * 4);
-    // window: padded coordinates origin (R*16, C*16), 48 rows x 12 dwords
-    const bool interior = (R > 0) && (C > 0) && (R < g.sh - 1) && (C < g.sw - 1);
-    for (int j = l; j < 48 * 12; j += 64) {
-        const int wr = j / 12, wc = j % 12;
-        uint32_t v;
-        if (interior) v = *(const uint32_t*)(P + (R * 16 - 16 + wr) * g.W + C * 16 - 16 + wc * 4);
-        else {
-            v = 0;
-#pragma unroll
-            for (int q = 0; q < 4; q++) v |= (uint32_t)pad_fetch(P, g.W, g.H, 16, R * 16 + wr, C * 16 + wc * 4 + q) << (8 * q);
-        }
-        win[wr * (kWinStride / 4) + wc] = v;
-    }
-    __builtin_amdgcn_wave_barrier();
-    // SADs of the union candidates: lane handles p = l, l+64, and everyone redundantly p = 128
-    for (int p = l; p < c_me.n_union; p += 64) {
-        const int ox = 16 + c_me.un_dx[p], oy = 16 + c_me.un_dy[p];
-        const int a = ox >> 2, sh = ox & 3;
-        uint32_t sad = 0;
-#pragma unroll 4
-        for (int i = 0; i < 16; i++) {
-            const uint32_t* wrow = win + (oy + i) * (kWinStride / 4) + a;
-            const uint32_t w0 = wrow[0], w1 = wrow[1], w2 = wrow[2], w3 = wrow[3], w4 = wrow[4];
-            sad = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w1, w0, sh), curl[i * 4 + 0], sad);
-            sad = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w2, w1, sh), curl[i * 4 + 1], sad);
-            sad = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w3, w2, sh), curl[i * 4 + 2], sad);
-            sad = __builtin_amdgcn_sad_u8(__builtin_amdgcn_alignbyte(w4, w3, sh), curl[i * 4 + 3], sad);
-        }
-        s_sad[wave][p] = (int)sad;
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint32_t ent = 0;
-    for (int s = 0; s < 4; s++) {
-        const int u = c_me.walk_u[s][l];
-        const int v = s_sad[wave][u];
-        const unsigned long long z = __ballot(v == 0);
-        int kbest, iters;
-        const unsigned long long z2 = z & (z - 1);
-        if (z2) { kbest = __builtin_ctzll(z2); iters = kbest + 1; }           // break on the second zero (ENC:2136-2141)
-        else    { kbest = wave_min((v << 6) | l) & 63; iters = 64; }          // first strict minimum (ENC:2130)
-        const int ub = c_me.walk_u[s][kbest];
-        const int mvx = -c_me.un_dx[ub], mvy = -c_me.un_dy[ub];               // mv = cur - best (ENC:2145-2146)
-        const uint32_t e = (uint32_t)(mvx & 0xff) | ((uint32_t)(mvy & 0xff) << 8) | ((uint32_t)((s + iters) & 3) << 16);
-        if (l == s) ent = e;
-    }
-    if (l < 4) b.me_ent[((long long)slot * g.nmb + mb) * 4 + l] = ent;
-}
-
-// Resolve the search-direction state along the macroblock raster (it is carried from MB to MB and only changes on
-// an early break, ENC:2095 vs 2106-2109), emit raw motion vectors and their differential coding (mvPrediction,
-// ENC:2353-2425, including the `(y1>x3)` typo).  One wave per P frame.
-__global__ __launch_bounds__(64) void k_me_resolve(Geo g, FrameSel fs, DevBufs b)
-{
-    extern __shared__ int8_t s_mv[];                      // [nmb][2] raw motion vectors of this frame
-    const int slot = fs.first + blockIdx.x * fs.stride;
-    const int l = lane_id();
-    const uint32_t* ent = b.me_ent + (long long)slot * g.nmb * 4;
-    int8_t* mv = b.mv + (long long)slot * g.nmb * 2;
-    int8_t* mvd = b.mvd + (long long)slot * g.nmb * 2;
-    // fast path: no macroblock changes the state
-    bool same = true;
-    for (int n = l; n < g.nmb; n += 64)
-#pragma unroll
-        for (int s = 0; s < 4; s++) same = same && (((ent[n * 4 + s] >> 16) & 3) == (uint32_t)s);
-    if (__ballot(!same) == 0) {
-        for (int n = l; n < g.nmb; n += 64) { uint32_t e = ent[n * 4]; s_mv[n * 2] = (int8_t)(e & 0xff); s_mv[n * 2 + 1] = (int8_t)((e >> 8) & 0xff); }
-    } else if (l == 0) {
-        int s = 0;
-        for (int n = 0; n < g.nmb; n++) {
-            uint32_t e = ent[n * 4 + s];
-            s_mv[n * 2] = (int8_t)(e & 0xff); s_mv[n * 2 + 1] = (int8_t)((e >> 8) & 0xff);
-            s = (e >> 16) & 3;
-        }
-    }
-    __syncthreads();
-    for (int n = l; n < g.nmb; n += 64) {
-        int px, py;
-        const int sw = g.sw;
-        if (n == 0) { px = 8; py = 8; }
-        else if (n / sw == 0) { px = s_mv[(n - 1) * 2]; py = s_mv[(n - 1) * 2 + 1]; }
-        else if (n % sw == 0) { px = s_mv[(n - sw) * 2]; py = s_mv[(n - sw) * 2 + 1]; }
-        else {
-            const int i1 = n - 1;
-            const int i2 = (n % sw == sw - 1) ? n - sw - 1 : n - sw;
-            const int i3 = (n % sw == sw - 1) ? n - sw : n - sw + 1;
-            const int x1 = s_mv[i1 * 2], x2 = s_mv[i2 * 2], x3 = s_mv[i3 * 2];
-            const int y1 = s_mv[i1 * 2 + 1], y2 = s_mv[i2 * 2 + 1], y3 = s_mv[i3 * 2 + 1];
-            px = median3(x1, x2, x3);
-            if ((y1 > y2) && (y1 > y3))      py = (y2 > y3) ? y2 : y3;
-            else if ((y2 > y1) && (y2 > y3)) py = (y1 > x3) ? y1 : y3;        // the reference's typo, kept (ENC:2399)
-            else                              py = (y1 > y2) ? y1 : y2;
-        }
-        mv[n * 2] = s_mv[n * 2]; mv[n * 2 + 1] = s_mv[n * 2 + 1];
-        mvd[n * 2] = (int8_t)(s_mv[n * 2] - px);
-        mvd[n * 2 + 1] = (int8_t)(s_mv[n * 2 + 1] - py);
-    }
-}
-
+#include "icsp_me.hip.inc"
 #include "icsp_blk8.hip.inc"
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -377,6 +260,7 @@ struct icsp_ctx {
     DevBufs b;
     uint8_t* d_frames;
     bool keep_coef, profiling;
+    unsigned prof_mask;               // which kernels get HIP events (icsp_profile_enable's argument, bit k = kernel k)
     std::vector<EvPair> ev_pending;
     std::vector<EvPair> ev_pool;
     double prof_ms[ICSP_K_COUNT];
@@ -410,7 +294,7 @@ void build_me_tables(MeTables& t)
 
 template <typename F> int launch_timed(icsp_ctx* ctx, int kernel, hipStream_t st, F&& f)
 {
-    if (!ctx->profiling) { f(); return 0; }
+    if (!ctx->profiling || !((ctx->prof_mask >> kernel) & 1u)) { f(); return 0; }
     EvPair e;
     if (!ctx->ev_pool.empty()) { e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
     else { if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return ICSP_ERR_HIP; }
@@ -488,10 +372,11 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         if (Gi == 0) break;
         FrameSel fs{ first + i, L, Gi };
         const long long nmbs = (long long)Gi * g.nmb, nblk = nmbs * 6;
-        launch_timed(ctx, ICSP_K_ME_SAD, st, [&] { hipLaunchKernelGGL(k_me_sad, dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, st, g, fs, b); });
-        launch_timed(ctx, ICSP_K_ME_RESOLVE, st, [&] { hipLaunchKernelGGL(k_me_resolve, dim3(Gi), dim3(64), (size_t)g.nmb * 2, st, g, fs, b); });
-        launch_timed(ctx, ICSP_K_BLOCK_SUMS, st, [&] { hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
-        launch_timed(ctx, ICSP_K_DC_CHAIN, st, [&] { hipLaunchKernelGGL(k_dc_chain, dim3(Gi, 3), dim3(256), (size_t)g.nmb * 4 * 2, st, g, fs, b, 0); });
+        launch_timed(ctx, ICSP_K_ME, st, [&] {
+            hipLaunchKernelGGL(k_me<false>, dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, st, g, fs, b);
+            hipLaunchKernelGGL(k_me<true>, dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, st, g, fs, b);
+        });
+        launch_timed(ctx, ICSP_K_FRAME_SERIAL, st, [&] { hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(256), ((size_t)g.nmb * 15 + 15) & ~(size_t)15, st, g, fs, b); });
         launch_timed(ctx, ICSP_K_RESIDUAL, st, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
     }
     HIPCHK(hipGetLastError());
@@ -538,7 +423,7 @@ const char* icsp_last_error(const icsp_ctx_t* ctx) { return ctx ? ctx->err.c_str
 
 const char* icsp_kernel_name(int k)
 {
-    static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_block_sums", "k_dc_chain", "k_residual", "k_me_sad", "k_me_resolve" };
+    static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_block_sums", "k_dc_chain", "k_residual", "k_me", "k_frame_serial" };
     return (k >= 0 && k < ICSP_K_COUNT) ? names[k] : "?";
 }
 
@@ -547,7 +432,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if (!out || !p) return ICSP_ERR_UNENOUGH_PARAM;
     *out = nullptr;
     if (p->width % 16 || p->height % 16 || p->width < 32 || p->width > 4096 || p->height < 16 || p->height > 2304 ||
-        (p->width / 16) * (p->height / 16) > 16384 ||     /* k_dc_chain keeps 8 bytes of LDS per macroblock */
+        (p->width / 16) * (p->height / 16) > 8704 ||      /* k_frame_serial keeps 15 bytes of LDS per macroblock */
         p->qp_dc <= 0 || p->qp_ac <= 0 || p->intra_period < 0 || max_frames <= 0)
         return ICSP_ERR_UNCORRECT_PARAM;
     int ndev = 0;
@@ -556,7 +441,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     icsp_ctx* ctx = new (std::nothrow) icsp_ctx();
     if (!ctx) return ICSP_ERR_MEM_ALLOC;
     ctx->p = *p; ctx->device = device_id; ctx->max_frames = max_frames;
-    ctx->keep_coef = false; ctx->profiling = false;
+    ctx->keep_coef = false; ctx->profiling = false; ctx->prof_mask = 0;
     memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms)); memset(ctx->prof_n, 0, sizeof(ctx->prof_n));
     Geo& g = ctx->g;
     g.W = p->width; g.H = p->height; g.sw = g.W / 16; g.sh = g.H / 16; g.nmb = g.sw * g.sh;
@@ -578,7 +463,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     // k_dc_chain stages one plane's block sums in dynamic LDS: up to 8 bytes per macroblock (luma), 128 KiB at the size cap
-    if ((e = hipFuncSetAttribute((const void*)k_dc_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)) != hipSuccess)
+    if ((e = hipFuncSetAttribute((const void*)k_dc_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)) != hipSuccess ||
+        (e = hipFuncSetAttribute((const void*)k_frame_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return fail(ICSP_ERR_MEM_ALLOC, "hipMalloc " #ptr, e)
     ALLOC(ctx->d_frames, nf * g.fsz);
@@ -592,6 +478,9 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ALLOC(ctx->b.imode, nf * nmb * 4);
     ALLOC(ctx->b.me_ent, nf * nmb * 4 * sizeof(uint32_t));
     ALLOC(ctx->b.sums, nf * nmb * 6 * sizeof(int16_t));
+    ALLOC(ctx->b.me_sums, nf * nmb * 24 * sizeof(int16_t));
+    ALLOC(ctx->b.me_flag, nf * sizeof(int));
+    hipMemsetAsync(ctx->b.me_flag, 0, nf * sizeof(int), ctx->stream);
     ALLOC(ctx->b.dcpred, nf * nmb * 6 * sizeof(int16_t));
 #undef ALLOC
     hipMemsetAsync(ctx->b.mpm, 0, nf * nmb * 4, ctx->stream);
@@ -614,7 +503,7 @@ int icsp_destroy(icsp_ctx_t* ctx)
     for (auto& e : ctx->ev_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : ctx->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     hipFree(ctx->d_frames); hipFree(ctx->b.recon); hipFree(ctx->b.levels); hipFree(ctx->b.acflag); hipFree(ctx->b.mpm);
-    hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.sums);
+    hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.sums); hipFree(ctx->b.me_sums); hipFree(ctx->b.me_flag);
     hipFree(ctx->b.dcpred); hipFree(ctx->b.coef);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
@@ -719,7 +608,13 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first, int n, double* coef)
     return ICSP_OK;
 }
 
-int icsp_profile_enable(icsp_ctx_t* ctx, int on) { if (!ctx) return ICSP_ERR_UNENOUGH_PARAM; ctx->profiling = on != 0; return ICSP_OK; }
+int icsp_profile_enable(icsp_ctx_t* ctx, int on)
+{
+    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ctx->profiling = on != 0;
+    ctx->prof_mask = (on == 1) ? 0xffffffffu : ((unsigned)on >> 1);     // 1 = every kernel; otherwise bit (k+1) selects kernel k
+    return ICSP_OK;
+}
 
 int icsp_profile_reset(icsp_ctx_t* ctx)
 {

@@ -17,7 +17,7 @@
  *   mpm_mode  uint8  [n][nMB][4]        bit0 MPMFlag, bit1 intraPredMode (I frames; 0 on P frames) (ENC:987-997)
  *   mvd       int8   [n][nMB][2]        differential motion vector x,y = bd.mv after mvPrediction (ENC:2353; 0 on I frames)
  *   recon     uint8  [n][W*H*3/2]       reconstructedY/Cb/Cr — what checkResultFrames dumps to test_yuv.yuv (ENC:6408-6410)
- * nMB = (W/16)*(H/16) <= 16384, macroblocks in raster order.  W, H multiples of 16, 32 <= W <= 4096, 16 <= H <= 2304.
+ * nMB = (W/16)*(H/16) <= 8704 (e.g. 2048x1088), macroblocks in raster order.  W, H multiples of 16, 32 <= W <= 4096, 16 <= H <= 2304.
  *
  * Errors: every function returns 0 (= reference SUCCESS, ICSP_Codec_Encoder.h:33-39) or a positive
  * icsp_status code; nothing calls exit().  There is NO CPU fallback: without a usable HIP device
@@ -94,7 +94,9 @@ int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
 
 /* ---- per-kernel timing with HIP events on the launch stream ---------------------------------- */
-enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_BLOCK_SUMS, ICSP_K_DC_CHAIN, ICSP_K_RESIDUAL, ICSP_K_ME_SAD, ICSP_K_ME_RESOLVE, ICSP_K_COUNT };
+enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_BLOCK_SUMS, ICSP_K_DC_CHAIN, ICSP_K_RESIDUAL, ICSP_K_ME, ICSP_K_FRAME_SERIAL, ICSP_K_COUNT };
+/* on: 0 = off, 1 = time every kernel, otherwise a mask with bit (k+1) set for each kernel k to time (events cost a few
+ * microseconds per launch, so the bench times only the dominant kernel inside its timed region). */
 int icsp_profile_enable(icsp_ctx_t* ctx, int on);
 int icsp_profile_reset(icsp_ctx_t* ctx);
 /* Sums over launches since the last reset; syncs the stream. */
