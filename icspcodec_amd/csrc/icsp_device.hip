@@ -69,6 +69,22 @@ struct MeTables {
 };
 __constant__ MeTables c_me;
 
+#ifdef ICSP_DIAG
+// Diagnostic build only (tools/diag_intra.hip): per-phase shader-cycle shares of one wave, never in the product build.
+__device__ unsigned long long g_diag[16];
+#define DIAG_DECL unsigned long long dg_t0 = 0, dg_acc[8] = {0,0,0,0,0,0,0,0}; const bool dg_on = (blockIdx.x == 0 && threadIdx.x < 64);
+#define DIAG_START if (dg_on) { __builtin_amdgcn_sched_barrier(0); dg_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
+#define DIAG_STAMP(n) if (dg_on) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); dg_acc[n] += t_ - dg_t0; dg_t0 = t_; __builtin_amdgcn_sched_barrier(0); }
+#define DIAG_END if (dg_on && (threadIdx.x == 0)) { for (int z_ = 0; z_ < 8; z_++) g_diag[z_] = dg_acc[z_]; g_diag[8] = __builtin_amdgcn_s_memrealtime() - dg_rt0; g_diag[9] = __builtin_amdgcn_s_memtime() - dg_c0; }
+#define DIAG_BEGIN unsigned long long dg_rt0 = __builtin_amdgcn_s_memrealtime(), dg_c0 = __builtin_amdgcn_s_memtime();
+#else
+#define DIAG_DECL
+#define DIAG_START
+#define DIAG_STAMP(n)
+#define DIAG_END
+#define DIAG_BEGIN
+#endif
+
 // ------------------------------------------------------------------------------------------------ geometry
 struct Geo {
     int W, H, sw, sh, nmb, cols8, rows8, cw, ch;
@@ -121,6 +137,7 @@ __device__ __forceinline__ int median3(int a, int b, int c)   // the reference's
     else if ((b > a) && (b > c)) return (a > c) ? a : c;
     else return (a > b) ? a : b;
 }
+__device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }   // same value as median3, branch-free (v_med3_i32)
 __device__ __forceinline__ int clip255(int t) { return min(max(t, 0), 255); }
 
 // ------------------------------------------------------------------------------------------------ prediction fetch
@@ -181,6 +198,8 @@ __global__ __launch_bounds__(256) void k_block_sums(Geo g, FrameSel fs, DevBufs 
     if (l == 0) b.sums[((long long)slot * g.nmb + mb) * 6 + k] = (int16_t)s;
 }
 
+#include "icsp_me.hip.inc"
+
 // ------------------------------------------------------------------------------------------------ DC chain
 // Serial DC-DPCM (DPCM_DC_block ENC:3643, IDPCM_DC_block 3991, CDPCM_DC_block 4420, CIDPCM_DC_block 4515) on block
 // sums, one workgroup of 256 threads per (frame, plane).  All sums of the plane are first turned into unpredicted DC
@@ -209,6 +228,8 @@ __global__ __launch_bounds__(256) void k_dc_chain(Geo g, FrameSel fs, DevBufs b,
         const int nsteps = cols + 2 * (rows - 1);
         const int q = g.qdc;
         const uint32_t mg = g.mdc;
+        if (rows <= 64) { if (luma) dc_chain_rows64<true>(s_sp, cols, rows, q, mg, l); else dc_chain_rows64<false>(s_sp, cols, rows, q, mg, l); }
+        else
         for (int t = 0; t < nsteps; t++) {
             int r_lo = t - (cols - 1); r_lo = (r_lo <= 0) ? 0 : (r_lo + 1) >> 1;
             const int r_hi = min(rows - 1, t >> 1);
@@ -241,7 +262,6 @@ __global__ __launch_bounds__(256) void k_dc_chain(Geo g, FrameSel fs, DevBufs b,
     }
 }
 
-#include "icsp_me.hip.inc"
 #include "icsp_blk8.hip.inc"
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -373,8 +393,8 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         FrameSel fs{ first + i, L, Gi };
         const long long nmbs = (long long)Gi * g.nmb, nblk = nmbs * 6;
         launch_timed(ctx, ICSP_K_ME, st, [&] {
-            hipLaunchKernelGGL(k_me<false>, dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, st, g, fs, b);
-            hipLaunchKernelGGL(k_me<true>, dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, st, g, fs, b);
+            hipLaunchKernelGGL((k_me<false, 4>), dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, st, g, fs, b);
+            hipLaunchKernelGGL((k_me<true, 16>), dim3((unsigned)((nmbs + 15) / 16)), dim3(1024), 0, st, g, fs, b);
         });
         launch_timed(ctx, ICSP_K_FRAME_SERIAL, st, [&] { hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(256), ((size_t)g.nmb * 15 + 15) & ~(size_t)15, st, g, fs, b); });
         launch_timed(ctx, ICSP_K_RESIDUAL, st, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
