@@ -21,7 +21,7 @@ SYMBOLS = [
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream",
 ]
-KERNELS = ["k_intra_luma", "k_block_sums", "k_dc_chain", "k_residual", "k_me", "k_frame_serial"]
+KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial"]
 
 
 class Params(C.Structure):

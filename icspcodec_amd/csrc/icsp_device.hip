@@ -98,7 +98,6 @@ struct DevBufs {
     int16_t* levels; uint8_t* acflag; uint8_t* mpm; int8_t* mvd;
     int8_t* mv; uint8_t* imode;       // debug taps / inter-kernel data
     uint32_t* me_ent;                 // [slot][nmb][4] packed (mvx, mvy, next state)
-    int16_t* sums;                    // [slot][nmb][6] residual block sums (I-frame chroma path)
     int* me_flag;                     // [slot] set by k_me<false> when a macroblock of the frame broke out of its walk early
     int16_t* me_sums;                 // [slot][nmb][4][6] residual block sums of a P-frame MB for each search state
     int16_t* dcpred;                  // [slot][nmb][6] DC predictors
@@ -152,114 +151,63 @@ __device__ __forceinline__ int pad_fetch(const uint8_t* plane, int w, int h, int
     return zero ? 0 : v;
 }
 
-// Residual sample + prediction for the lane's pixel of block (slot, mb, k).  inter=false: chroma of an I frame
-// (no prediction, ENC:4347-4349).  inter=true: motion compensated (ENC:2156-2226 luma, 2500-2557 chroma, mv/2).
-__device__ __forceinline__ void block_sample(const Geo& g, const DevBufs& b, int slot, int prev_slot, int mb, int k,
-                                             bool inter, int r, int c, int& cur, int& pred)
-{
-    const int R = mb / g.sw, C = mb % g.sw;
-    const uint8_t* F = b.frames + slot * g.fsz;
-    if (k < 4) {
-        const int y = R * 16 + (k >> 1) * 8 + r, x = C * 16 + (k & 1) * 8 + c;
-        cur = F[y * g.W + x];
-        pred = 0;
-        if (inter) {
-            const int8_t* mv = b.mv + ((long long)slot * g.nmb + mb) * 2;
-            pred = pad_fetch(b.recon + prev_slot * g.fsz, g.W, g.H, 16, y - mv[1] + 16, x - mv[0] + 16);
-        }
-    } else {
-        const long long off = (long long)g.W * g.H + (k == 5 ? g.cw * g.ch : 0);
-        const int y = R * 8 + r, x = C * 8 + c;
-        cur = F[off + y * g.cw + x];
-        pred = 0;
-        if (inter) {
-            const int8_t* mv = b.mv + ((long long)slot * g.nmb + mb) * 2;
-            pred = pad_fetch(b.recon + prev_slot * g.fsz + off, g.cw, g.ch, 8, y - mv[1] / 2 + 8, x - mv[0] / 2 + 8);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ block sums
-// S = sum of the 64 residual samples of a block.  The DC coefficient is ((S*irt2)*irt2)*0.25 exactly (the u=0 /
-// v=0 cosine row is 1.0, so both passes are exact integer sums), which lets the serial DC-DPCM chain run on S
-// before the parallel transform kernel.
-__global__ __launch_bounds__(256) void k_block_sums(Geo g, FrameSel fs, DevBufs b, int kbase, int kcount, int inter)
-{
-    const long long id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long total = (long long)fs.count * g.nmb * kcount;
-    if (id >= total) return;
-    const int k = kbase + (int)(id % kcount);
-    const int mb = (int)((id / kcount) % g.nmb);
-    const int slot = fs.first + (int)(id / ((long long)kcount * g.nmb)) * fs.stride;
-    const int l = lane_id();
-    int cur, pred;
-    block_sample(g, b, slot, slot - 1, mb, k, inter != 0, l >> 3, l & 7, cur, pred);
-    const int s = wave_sum(cur - pred);
-    if (l == 0) b.sums[((long long)slot * g.nmb + mb) * 6 + k] = (int16_t)s;
-}
-
 #include "icsp_me.hip.inc"
 
-// ------------------------------------------------------------------------------------------------ DC chain
-// Serial DC-DPCM (DPCM_DC_block ENC:3643, IDPCM_DC_block 3991, CDPCM_DC_block 4420, CIDPCM_DC_block 4515) on block
-// sums, one workgroup of 256 threads per (frame, plane).  All sums of the plane are first turned into unpredicted DC
-// coefficients in LDS (parallel); then wave 0 walks the 2:1 wavefront with only LDS traffic and ~10 dependent ALU ops
-// per step on the chain; finally the predictors are stored coalesced.
-// sums of the plane are staged in LDS as int16 and overwritten in place by the predictors (2 bytes per block)
-__global__ __launch_bounds__(256) void k_dc_chain(Geo g, FrameSel fs, DevBufs b, int chain_base)
+// ------------------------------------------------------------------------------------------------ I-frame chroma DC chain
+// Chroma of an I frame is transformed without pixel prediction (ENC:4347-4349), so only its DC-DPCM is serial
+// (CDPCM_DC_block ENC:4420-4514, CIDPCM_DC_block ENC:4515-4609).  One workgroup per (frame, plane): block sums S of the
+// raw pixels (8 lanes per block, v_sad_u8 against 0) go to LDS -- the DC coefficient is ((S*irt2)*irt2)*0.25 exactly,
+// both passes of the u=0/v=0 cosine row being exact integer sums -- then one wave walks the chain and the predictors
+// are written back for k_residual8.
+__global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_rec[2][512];
     const int slot = fs.first + blockIdx.x * fs.stride;
-    const int chain = chain_base + blockIdx.y;                 // 0 = luma 8x8 grid, 1 = Cb, 2 = Cr
-    const bool luma = chain == 0;
-    const int cols = luma ? g.cols8 : g.sw, rows = luma ? g.rows8 : g.sh, nblk = cols * rows;
-    int16_t* s_sp = (int16_t*)s_dyn;                           // [nblk] grid order: block sum in, predictor out
+    const int pl = blockIdx.y;                                 // 0 = Cb, 1 = Cr
+    const int cols = g.sw, rows = g.sh, nblk = g.nmb;
+    int16_t* s_sp = (int16_t*)s_dyn;                           // [nmb] block sum in, predictor out
     const long long fb = (long long)slot * g.nmb;
-    for (int n = threadIdx.x; n < nblk; n += 256) {
-        const int r = n / cols, c = n % cols;
-        const int mb = luma ? (r >> 1) * g.sw + (c >> 1) : n;
-        const int k = luma ? (r & 1) * 2 + (c & 1) : 3 + chain;
-        s_sp[n] = b.sums[(fb + mb) * 6 + k];
+    const uint8_t* plane = b.frames + slot * g.fsz + (long long)g.W * g.H + (long long)pl * g.cw * g.ch;
+    const int i = threadIdx.x & 7;
+    for (int n0 = 0; n0 < nblk; n0 += 32) {
+        const int n = min(n0 + (int)(threadIdx.x >> 3), nblk - 1);
+        const uint2 row = *(const uint2*)(plane + ((n / cols) * 8 + i) * g.cw + (n % cols) * 8);
+        int v = (int)__builtin_amdgcn_sad_u8(row.y, 0, __builtin_amdgcn_sad_u8(row.x, 0, 0));
+        v += dpp<0xB1>(v); v += dpp<0x4E>(v); v += dpp<0x141>(v);      // sum over the 8 rows of the block
+        if (i == 0) s_sp[n] = (int16_t)v;
     }
     __syncthreads();
     if (threadIdx.x < 64) {
         const int l = threadIdx.x;
-        const int nsteps = cols + 2 * (rows - 1);
         const int q = g.qdc;
         const uint32_t mg = g.mdc;
-        if (rows <= 64) { if (luma) dc_chain_rows64<true>(s_sp, cols, rows, q, mg, l); else dc_chain_rows64<false>(s_sp, cols, rows, q, mg, l); }
-        else
-        for (int t = 0; t < nsteps; t++) {
-            int r_lo = t - (cols - 1); r_lo = (r_lo <= 0) ? 0 : (r_lo + 1) >> 1;
-            const int r_hi = min(rows - 1, t >> 1);
-            for (int r = r_lo + l; r <= r_hi; r += 64) {
-                const int c = t - 2 * r;
-                const int cl = max(c - 1, 0), cr = min(c + 1, cols - 1), ru = (r + 1) & 1, rc = r & 1;
-                const int L = s_rec[rc][cl], U = s_rec[ru][c], UL = s_rec[ru][cl], UR = s_rec[ru][cr];
-                const bool lul = luma ? (((r & 1) && (c & 1)) || c == cols - 1) : (c == cols - 1);
-                const int third = lul ? UL : UR;
-                const int med = max(min(L, U), min(max(L, U), third));
-                const int p = (r == 0 && c == 0) ? 1024 : (r == 0) ? L : (c == 0) ? U : med;
-                const double S = (double)s_sp[r * cols + c];
-                // ((S*irt2)*irt2)*0.25 == DCT_block's [0][0] output: the u=0 / v=0 cosine row is 1.0, so both passes are exact sums
-                const double dc = ((S * kIrt2) * kIrt2) * (1. / 4.) - p;
-                const int t0 = luma ? (int)(dc + 0.5) : (int)floor(dc + 0.5);
-                const uint32_t a = (uint32_t)abs(t0);
-                const int lv = (int)((q == 1) ? a : __umulhi(a, mg));
-                s_rec[rc][c] = ((t0 < 0) ? -lv : lv) * q + p;
-                s_sp[r * cols + c] = (int16_t)p;
+        if (rows <= 64) dc_chain_rows64<false>(s_sp, cols, rows, q, mg, l);
+        else {
+            const int nsteps = cols + 2 * (rows - 1);
+            for (int t = 0; t < nsteps; t++) {
+                int r_lo = t - (cols - 1); r_lo = (r_lo <= 0) ? 0 : (r_lo + 1) >> 1;
+                const int r_hi = min(rows - 1, t >> 1);
+                for (int r = r_lo + l; r <= r_hi; r += 64) {
+                    const int c = t - 2 * r;
+                    const int cl = max(c - 1, 0), cr = min(c + 1, cols - 1), ru = (r + 1) & 1, rc = r & 1;
+                    const int L = s_rec[rc][cl], U = s_rec[ru][c], UL = s_rec[ru][cl], UR = s_rec[ru][cr];
+                    const int med = med3i(L, U, (c == cols - 1) ? UL : UR);
+                    const int p = (r == 0 && c == 0) ? 1024 : (r == 0) ? L : (c == 0) ? U : med;
+                    const double S = (double)s_sp[r * cols + c];
+                    const double dc = ((S * kIrt2) * kIrt2) * (1. / 4.) - p;
+                    const int t0 = (int)floor(dc + 0.5);
+                    const uint32_t a = (uint32_t)abs(t0);
+                    const int lv = (int)((q == 1) ? a : __umulhi(a, mg));
+                    s_rec[rc][c] = ((t0 < 0) ? -lv : lv) * q + p;
+                    s_sp[r * cols + c] = (int16_t)p;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
     }
     __syncthreads();
-    for (int n = threadIdx.x; n < nblk; n += 256) {
-        const int r = n / cols, c = n % cols;
-        const int mb = luma ? (r >> 1) * g.sw + (c >> 1) : n;
-        const int k = luma ? (r & 1) * 2 + (c & 1) : 3 + chain;
-        b.dcpred[(fb + mb) * 6 + k] = s_sp[n];
-    }
+    for (int n = threadIdx.x; n < nblk; n += 256) b.dcpred[(fb + n) * 6 + 4 + pl] = s_sp[n];
 }
 
 #include "icsp_blk8.hip.inc"
@@ -379,8 +327,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         hipStreamWaitEvent(s2, ctx->ev_fork, 0);
         launch_timed(ctx, ICSP_K_INTRA_LUMA, st, [&] { launch_intra_luma(ctx, g, fs, b, G, st); });
         const long long nblk = (long long)G * g.nmb * 2;
-        launch_timed(ctx, ICSP_K_BLOCK_SUMS, s2, [&] { hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((nblk + 3) / 4)), dim3(256), 0, s2, g, fs, b, 4, 2, 0); });
-        launch_timed(ctx, ICSP_K_DC_CHAIN, s2, [&] { hipLaunchKernelGGL(k_dc_chain, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b, 1); });
+        launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s2, g, fs, b, 4, 2, 0); });
         hipEventRecord(ctx->ev_join, s2);
         hipStreamWaitEvent(st, ctx->ev_join, 0);
@@ -443,7 +390,7 @@ const char* icsp_last_error(const icsp_ctx_t* ctx) { return ctx ? ctx->err.c_str
 
 const char* icsp_kernel_name(int k)
 {
-    static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_block_sums", "k_dc_chain", "k_residual", "k_me", "k_frame_serial" };
+    static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial" };
     return (k >= 0 && k < ICSP_K_COUNT) ? names[k] : "?";
 }
 
@@ -478,13 +425,15 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
     auto fail = [&](int code, const char* what, hipError_t e) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); icsp_destroy(ctx); return code; };
     hipError_t e;
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
-    if ((e = hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
+    // the main stream carries the latency-bound kernels and gets the higher priority; stream2 (I-frame chroma) fills in
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
+    if ((e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
-    // k_dc_chain stages one plane's block sums in dynamic LDS: up to 8 bytes per macroblock (luma), 128 KiB at the size cap
-    if ((e = hipFuncSetAttribute((const void*)k_dc_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 132 * 1024)) != hipSuccess ||
-        (e = hipFuncSetAttribute((const void*)k_frame_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)) != hipSuccess)
+    // k_frame_serial stages a frame's block sums, vectors and states in dynamic LDS: 15 bytes per macroblock
+    if ((e = hipFuncSetAttribute((const void*)k_frame_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return fail(ICSP_ERR_MEM_ALLOC, "hipMalloc " #ptr, e)
     ALLOC(ctx->d_frames, nf * g.fsz);
@@ -497,7 +446,6 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ALLOC(ctx->b.mv, nf * nmb * 2);
     ALLOC(ctx->b.imode, nf * nmb * 4);
     ALLOC(ctx->b.me_ent, nf * nmb * 4 * sizeof(uint32_t));
-    ALLOC(ctx->b.sums, nf * nmb * 6 * sizeof(int16_t));
     ALLOC(ctx->b.me_sums, nf * nmb * 24 * sizeof(int16_t));
     ALLOC(ctx->b.me_flag, nf * sizeof(int));
     hipMemsetAsync(ctx->b.me_flag, 0, nf * sizeof(int), ctx->stream);
@@ -523,7 +471,7 @@ int icsp_destroy(icsp_ctx_t* ctx)
     for (auto& e : ctx->ev_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : ctx->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     hipFree(ctx->d_frames); hipFree(ctx->b.recon); hipFree(ctx->b.levels); hipFree(ctx->b.acflag); hipFree(ctx->b.mpm);
-    hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.sums); hipFree(ctx->b.me_sums); hipFree(ctx->b.me_flag);
+    hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.me_sums); hipFree(ctx->b.me_flag);
     hipFree(ctx->b.dcpred); hipFree(ctx->b.coef);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);

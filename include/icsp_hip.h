@@ -94,7 +94,7 @@ int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
 
 /* ---- per-kernel timing with HIP events on the launch stream ---------------------------------- */
-enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_BLOCK_SUMS, ICSP_K_DC_CHAIN, ICSP_K_RESIDUAL, ICSP_K_ME, ICSP_K_FRAME_SERIAL, ICSP_K_COUNT };
+enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_CHROMA_DC, ICSP_K_RESIDUAL, ICSP_K_ME, ICSP_K_FRAME_SERIAL, ICSP_K_COUNT };
 /* on: 0 = off, 1 = time every kernel, otherwise a mask with bit (k+1) set for each kernel k to time (events cost a few
  * microseconds per launch, so the bench times only the dominant kernel inside its timed region). */
 int icsp_profile_enable(icsp_ctx_t* ctx, int on);
