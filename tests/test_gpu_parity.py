@@ -138,6 +138,29 @@ def test_other_geometry_non_cif():
         _cmp(got, po.encode_sequence(clip, w, h, 8, 8, 3), f"{w}x{h}: ")
 
 
+def test_hd_1088p_config5_geometry():
+    """BASELINE configs[4] geometry: 1920x1088 (1080 is not a multiple of 16, ENC:322), --intraPeriod 3 here.  Exercises the
+    paths CIF never takes: more wavefront blocks than one workgroup round (60 waves needed, 16 used), block rows > 64 in the
+    DC chains (LDS fallback), 8160 macroblocks per frame in the per-frame serial kernel."""
+    w, h = 1920, 1088
+    clip = clipgen.synth_clip("tablelike", 3, width=w, height=h)
+    enc = capi.Encoder(w, h, 16, 16, 3, max_frames=3)
+    got = enc.encode(clip)
+    enc.close()
+    _cmp(got, po.encode_sequence(clip, w, h, 16, 16, 3, nthreads=3), "1088p: ")
+
+
+def test_4cif_all_intra_and_size_limit():
+    w, h = 704, 576
+    clip = clipgen.synth_clip("mobilelike", 2, width=w, height=h)
+    enc = capi.Encoder(w, h, 8, 8, 0, max_frames=2)
+    got = enc.encode(clip)
+    enc.close()
+    _cmp(got, po.encode_sequence(clip, w, h, 8, 8, 0), "4CIF: ")
+    with pytest.raises(capi.IcspError):
+        capi.Encoder(4096, 2304)                    # 36864 macroblocks: beyond the 8704-macroblock limit of the header
+
+
 def test_errors_not_exit():
     with pytest.raises(capi.IcspError):
         capi.Encoder(350, 288)                      # width not a multiple of 16 (ENC:322-326 returns -1)
@@ -180,3 +203,20 @@ def test_full_baseline_configs_hashes(golden_dir):
         assert len(bs) == s["bin_bytes"] and hashlib.sha256(bs).hexdigest() == s["bin_sha256"], key
         seen += 1
     assert seen == 2
+
+
+def test_config4_all_twelve_clips_hashes(golden_dir):
+    """BASELINE configs[3]: the twelve CIF clips (11 x 300 f + 1 x 90 f), --intraPeriod 10, QP 16.  Each clip's .bin and
+    test_yuv.yuv SHA-256 equal what the reference CLI produced (tools/make_golden.py)."""
+    streams = json.load(open(os.path.join(golden_dir, "streams.json")))
+    todo = [s for s in streams if s["intra_period"] == 10 and s["qp"] == 16 and s["nframes"] >= 90 and "bin_sha256" in s]
+    assert len(todo) == 12
+    enc = capi.Encoder(W, H, 16, 16, 10, max_frames=300)
+    for s in todo:
+        clip = clipgen.synth_clip(s["clip"], s["nframes"])
+        assert hashlib.sha256(clip.tobytes()).hexdigest() == s["clip_sha256"]
+        o = enc.encode(clip)
+        assert hashlib.sha256(o["recon"].tobytes()).hexdigest() == s["recon_sha256"], s["clip"]
+        bs = capi.write_bitstream(W, H, 16, 16, 10, o["levels"], o["acflag"], o["mpm"], o["mvd"])
+        assert len(bs) == s["bin_bytes"] and hashlib.sha256(bs).hexdigest() == s["bin_sha256"], s["clip"]
+    enc.close()
