@@ -98,9 +98,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # test hooks (tests/test_gpu_bench.py runs the N>1 code path with two ranks on a one-GPU box): the driver never sets them
+    backend = os.environ.get("ICSP_BENCH_BACKEND", "nccl")
+    if "ICSP_BENCH_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["ICSP_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     def barrier():
         if world > 1:
@@ -128,7 +136,7 @@ def main():
         prof = {k: (v[0] / 3.0, v[1]) for k, v in enc.profile_get().items()}
         enc.profile(False)
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, prof, (dom_ms, dom_n)
@@ -160,7 +168,7 @@ def main():
     enc2.close()
     fps2 = world * NFRAMES * steps2 / dt2
 
-    cpu = None if a.no_cpu else cpu_baseline(rank)
+    cpu = None if (a.no_cpu or world > 1) else cpu_baseline(rank)      # CPU baseline: rank 0 at N=1 only
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -176,7 +184,7 @@ def main():
             traffic = None
     read_mean_ip = (BYTES_I_FRAME_READ + 9 * BYTES_P_FRAME_READ) / 10.0
     line = {
-        "metric": "CIF encode fps (all-intra, QP=16)", "value": round(fps, 1), "unit": "frames/s",
+        "metric": "CIF encode fps (all-intra QP=16; IPPP alongside in `ippp`)", "value": round(fps, 1), "unit": "frames/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "foremanlike_cif 352x288 300f, --intraPeriod 0 (all-intra), QP=16, per GPU (BASELINE configs[1])",

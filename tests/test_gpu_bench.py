@@ -1,0 +1,47 @@
+"""bench.py contract on the GPU box: one JSON line with the required keys at N=1, and the N>1 code path (barrier,
+max-over-ranks, aggregate value) exercised with two ranks sharing the only GPU (gloo for the tiny control traffic)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline"}
+
+
+def _last_json(out):
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1"], stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    d = _last_json(r.stdout)
+    assert REQUIRED <= set(d)
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "frames/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 1e4 and abs(d["value"] - 300 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 0.01
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["psnr_y_db"] > 25 and d["ippp"]["value"] > 1e4
+
+
+def test_two_ranks_weak_scaling_path():
+    env = dict(os.environ, ICSP_BENCH_BACKEND="gloo", ICSP_BENCH_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    # value is the aggregate over both ranks: 2 x 300 frames per step
+    assert abs(d["value"] - 2 * 300 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
