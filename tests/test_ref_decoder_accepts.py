@@ -58,3 +58,20 @@ def test_ippp_stream_is_accepted(tmp_path):
     for f in (0, 3):                       # I frames: luma exact
         assert np.array_equal(dec[f, : W * H], o["recon"][f, : W * H])
     assert abs(psnr - clipgen.psnr_y(clip, dec, W, H)) < 1e-3
+
+
+@pytest.mark.gpu
+def test_reference_decoder_accepts_gpu_stream(tmp_path):
+    """End to end on the GPU box: HIP encode -> host bit packer -> the reference's own decoder binary (prebuilt in oracle/_ref)."""
+    n, q, period = 6, 16, 3
+    clip = clipgen.synth_clip("tablelike", n)
+    enc = capi.Encoder(W, H, q, q, period, max_frames=n)
+    o = enc.encode(clip)
+    enc.close()
+    bs = capi.write_bitstream(W, H, q, q, period, o["levels"], o["acflag"], o["mpm"], o["mvd"])
+    dec, psnr = _decode(str(tmp_path), bs, clip, n, q, period)
+    for f in (0, 3):
+        assert np.array_equal(dec[f, : W * H], o["recon"][f, : W * H])
+    d = np.abs(dec.astype(int) - o["recon"].astype(int))
+    assert d.max() <= 2 and (d > 0).mean() < 0.02
+    assert abs(psnr - clipgen.psnr_y(clip, dec, W, H)) < 1e-3 and psnr > 25
