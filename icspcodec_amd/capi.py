@@ -19,9 +19,9 @@ SYMBOLS = [
     "icsp_create", "icsp_destroy", "icsp_strerror", "icsp_last_error", "icsp_encode_gop", "icsp_upload",
     "icsp_encode_resident", "icsp_sync", "icsp_download", "icsp_device_view", "icsp_download_debug",
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
-    "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream",
+    "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
 ]
-KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial"]
+KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack"]
 
 
 class Params(C.Structure):
@@ -69,6 +69,9 @@ def load() -> C.CDLL:
         lib.icsp_profile_reset.argtypes = [vp]
         lib.icsp_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         lib.icsp_write_bitstream.argtypes = [C.POINTER(Params), C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.icsp_pack_bits.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_uint64)]
+        lib.icsp_bitstream_assemble.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), vp, C.c_size_t,
+                                                C.POINTER(C.c_size_t)]
         _lib = lib
     return _lib
 
@@ -88,6 +91,24 @@ def write_bitstream(width, height, qp_dc, qp_ac, intra_period, levels, acflag, m
     out = np.zeros(cap, np.uint8)
     nbytes = C.c_size_t(0)
     rc = lib.icsp_write_bitstream(C.byref(p), n, _vp(lv), _vp(ac), _vp(mp), _vp(mv), _vp(out), cap, C.byref(nbytes))
+    if rc:
+        raise IcspError(lib.icsp_strerror(rc).decode())
+    return out[: nbytes.value].tobytes()
+
+
+def assemble_bitstream(width, height, qp_dc, qp_ac, intra_period, pieces) -> bytes:
+    """Host: header + bit-wise concatenation of `pieces` = [(bytes-like body, nbits), ...] in frame order + the reference's
+    final byte -> the .bin image (icsp_bitstream_assemble).  Needs no GPU."""
+    lib = load()
+    p = Params(width, height, qp_dc, qp_ac, intra_period)
+    bufs = [np.frombuffer(bytes(b), np.uint8) if not isinstance(b, np.ndarray) else np.ascontiguousarray(b, np.uint8) for b, _ in pieces]
+    k = len(pieces)
+    ptrs = (C.c_void_p * max(k, 1))(*[b.ctypes.data for b in bufs])
+    bits = (C.c_uint64 * max(k, 1))(*[int(nb) for _, nb in pieces])
+    cap = 14 + sum(int(nb) for _, nb in pieces) // 8 + 3
+    out = np.zeros(cap, np.uint8)
+    nbytes = C.c_size_t(0)
+    rc = lib.icsp_bitstream_assemble(C.byref(p), k, ptrs, bits, _vp(out), cap, C.byref(nbytes))
     if rc:
         raise IcspError(lib.icsp_strerror(rc).decode())
     return out[: nbytes.value].tobytes()
@@ -162,6 +183,19 @@ class Encoder:
 
     def keep_coef(self, on=True):
         self._chk(self.lib.icsp_debug_keep_coef(self.ctx, int(on)), "icsp_debug_keep_coef")
+
+    def pack_bits(self, first, n):
+        """Device bit packer on the encoded slots [first, first+n): (body bytes as uint8 array, bit count)."""
+        cap = self.lib.icsp_bitstream_bound(C.byref(self.params), n)
+        body = np.zeros(cap, np.uint8)
+        nbits = C.c_uint64(0)
+        self._chk(self.lib.icsp_pack_bits(self.ctx, first, n, _vp(body), cap, C.byref(nbits)), "icsp_pack_bits")
+        return body[: (nbits.value + 7) // 8], nbits.value
+
+    def pack_bitstream(self, first, n) -> bytes:
+        """The .bin image of slots [first, first+n) with the body packed on the device."""
+        p = self.params
+        return assemble_bitstream(p.width, p.height, p.qp_dc, p.qp_ac, p.intra_period, [self.pack_bits(first, n)])
 
     def download_coef(self, first, n):
         c = np.zeros((n, self.nmb, 6, 64), np.float64)

@@ -79,13 +79,9 @@ size_t icsp_bitstream_bound(const icsp_params_t* p, int n)
     return 14 + ((size_t)n * nmb * bits_per_mb) / 8 + 2;
 }
 
-int icsp_write_bitstream(const icsp_params_t* p, int n, const int16_t* levels, const uint8_t* acflag,
-                         const uint8_t* mpm_mode, const int8_t* mvd, uint8_t* out, size_t cap, size_t* out_bytes)
+static void write_header(const icsp_params_t* p, uint8_t* out)
 {
-    if (!p || !levels || !acflag || !mpm_mode || !mvd || !out || !out_bytes) return ICSP_ERR_UNENOUGH_PARAM;
-    if (cap < 15 || n < 0) return ICSP_ERR_UNCORRECT_PARAM;
-    memset(out, 0, cap);
-    // header: packed struct of 14 bytes (ICSP_Codec_Encoder.h:201-212), little-endian shorts
+    // packed struct of 14 bytes (ICSP_Codec_Encoder.h:201-212), little-endian shorts
     out[0] = 0; out[1] = 73; out[2] = 67; out[3] = 83; out[4] = 80;       // "\0ICSP" (ENC:4903)
     const uint16_t hh = (uint16_t)p->height, ww = (uint16_t)p->width;
     out[5] = (uint8_t)(hh & 0xff); out[6] = (uint8_t)(hh >> 8);
@@ -93,6 +89,47 @@ int icsp_write_bitstream(const icsp_params_t* p, int n, const int16_t* levels, c
     out[9] = (uint8_t)p->qp_dc; out[10] = (uint8_t)p->qp_ac; out[11] = 0;
     const uint16_t outro = (uint16_t)((p->intra_period & 0x3f) << 7);       // 6 bits of intraPeriod, then 7 zero bits (ENC:4910-4921)
     out[12] = (uint8_t)(outro & 0xff); out[13] = (uint8_t)(outro >> 8);
+}
+
+int icsp_bitstream_assemble(const icsp_params_t* p, int npieces, const uint8_t* const* pieces,
+                            const uint64_t* piece_bits, uint8_t* out, size_t cap, size_t* out_bytes)
+{
+    if (!p || !out || !out_bytes || npieces < 0 || (npieces > 0 && (!pieces || !piece_bits))) return ICSP_ERR_UNENOUGH_PARAM;
+    uint64_t total = 0;
+    for (int i = 0; i < npieces; i++) total += piece_bits[i];
+    const size_t body = (size_t)(total / 8) + 1;                       // fwrite(..., cntbits/8 + 1, ...) (ENC:4895, 5029)
+    if (cap < 14 + body + 1) return ICSP_ERR_RANGE;
+    memset(out, 0, 14 + body + 1);
+    write_header(p, out);
+    uint8_t* dst = out + 14;
+    uint64_t at = 0;                                                   // bits written so far
+    for (int i = 0; i < npieces; i++) {
+        const uint8_t* src = pieces[i];
+        const size_t nb = (size_t)((piece_bits[i] + 7) / 8);
+        const unsigned sh = (unsigned)(at & 7);
+        uint8_t* d = dst + (at >> 3);
+        if (sh == 0) memcpy(d, src, nb);
+        else for (size_t j = 0; j < nb; j++) { d[j] |= (uint8_t)(src[j] >> sh); d[j + 1] |= (uint8_t)(src[j] << (8 - sh)); }
+        at += piece_bits[i];
+        // drop the padding bits of this piece's last byte so the next piece can be OR-ed in
+        const unsigned keep = (unsigned)(at & 7);
+        dst[at >> 3] &= (uint8_t)(keep ? (0xff00u >> keep) : 0);
+        dst[(at >> 3) + 1] = 0;
+    }
+    // the reference shifts bits into each byte from the right, so a final partial byte holds its bits right-aligned
+    const unsigned r = (unsigned)(total & 7);
+    if (r) dst[total >> 3] = (uint8_t)(dst[total >> 3] >> (8 - r));
+    *out_bytes = 14 + body;
+    return ICSP_OK;
+}
+
+int icsp_write_bitstream(const icsp_params_t* p, int n, const int16_t* levels, const uint8_t* acflag,
+                         const uint8_t* mpm_mode, const int8_t* mvd, uint8_t* out, size_t cap, size_t* out_bytes)
+{
+    if (!p || !levels || !acflag || !mpm_mode || !mvd || !out || !out_bytes) return ICSP_ERR_UNENOUGH_PARAM;
+    if (cap < 15 || n < 0) return ICSP_ERR_UNCORRECT_PARAM;
+    memset(out, 0, cap);
+    write_header(p, out);
 
     BitWriter w{ out + 14, cap - 14, 0, false };
     const size_t nmb = (size_t)(p->width / 16) * (p->height / 16);

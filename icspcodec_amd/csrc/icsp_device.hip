@@ -211,11 +211,13 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
 }
 
 #include "icsp_blk8.hip.inc"
+#include "icsp_pack.hip.inc"
 
 // ------------------------------------------------------------------------------------------------ host side
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return ICSP_ERR_HIP; } } while (0)
 
 struct EvPair { hipEvent_t a, b; int kernel; };
+constexpr int kMaxPGroups = 3;
 
 } // namespace
 
@@ -225,7 +227,12 @@ struct icsp_ctx {
     int device, max_frames, intra_waves, n_cu;
     hipStream_t stream, stream2;      // stream2: I-frame chroma beside the luma wavefront kernel
     hipEvent_t ev_fork, ev_join;
+    int p_groups;                     // GOP groups whose P-step chains run on separate streams
+    hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
+    hipEvent_t ev_pjoin[kMaxPGroups];
     DevBufs b;
+    PackBufs pk;                      // device bit packer scratch + body buffer, allocated on first icsp_pack_bits
+    size_t pk_cap;                    // bytes of pk.out
     uint8_t* d_frames;
     bool keep_coef, profiling;
     unsigned prof_mask;               // which kernels get HIP events (icsp_profile_enable's argument, bit k = kernel k)
@@ -332,20 +339,39 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         hipEventRecord(ctx->ev_join, s2);
         hipStreamWaitEvent(st, ctx->ev_join, 0);
     }
-    // ---- steps 1..L-1: the i-th P frame of every GOP that has one
-    for (int i = 1; i < L; i++) {
-        int Gi = 0;
-        for (int gop = 0; gop < G; gop++) if (gop * L + i < n) Gi++;
-        if (Gi == 0) break;
-        FrameSel fs{ first + i, L, Gi };
-        const long long nmbs = (long long)Gi * g.nmb, nblk = nmbs * 6;
-        launch_timed(ctx, ICSP_K_ME, st, [&] {
-            hipLaunchKernelGGL((k_me<false, 4>), dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, st, g, fs, b);
-            hipLaunchKernelGGL((k_me<true, 16>), dim3((unsigned)((nmbs + 15) / 16)), dim3(1024), 0, st, g, fs, b);
-        });
-        launch_timed(ctx, ICSP_K_FRAME_SERIAL, st, [&] { hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(256), ((size_t)g.nmb * 15 + 15) & ~(size_t)15, st, g, fs, b); });
-        launch_timed(ctx, ICSP_K_RESIDUAL, st, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
+    // ---- steps 1..L-1: the i-th P frame of every GOP that has one.  A P step is a chain of dependent kernels of which
+    //      k_frame_serial is latency-bound (one workgroup per frame) and leaves most of the chip idle: the GOPs are split
+    //      into groups, each running its own chain on its own stream, so one group's serial kernel overlaps the others'
+    //      search and residual kernels.  Groups touch disjoint frames, hence disjoint slots of every buffer.
+    int NG = ctx->p_groups;
+    if (NG > G / 4) NG = G / 4;                        // keep every group's launches wide enough to be worth splitting
+    if (NG < 1) NG = 1;
+    if (L > 1 && NG > 1) {
+        hipEventRecord(ctx->ev_fork, st);
+        for (int k = 1; k < NG; k++) hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0);
     }
+    for (int i = 1; i < L; i++) {
+        bool any = false;
+        for (int k = 0; k < NG; k++) {
+            const int g0 = (int)((long long)G * k / NG), g1 = (int)((long long)G * (k + 1) / NG);
+            int Gi = 0;
+            for (int gop = g0; gop < g1; gop++) if (gop * L + i < n) Gi++;
+            if (Gi == 0) continue;
+            any = true;
+            hipStream_t sk = k == 0 ? st : ctx->pstream[k];
+            FrameSel fs{ first + g0 * L + i, L, Gi };
+            const long long nmbs = (long long)Gi * g.nmb, nblk = nmbs * 6;
+            launch_timed(ctx, ICSP_K_ME, sk, [&] {
+                hipLaunchKernelGGL((k_me<false, 4>), dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, sk, g, fs, b);
+                hipLaunchKernelGGL((k_me<true, 16>), dim3((unsigned)((nmbs + 15) / 16)), dim3(1024), 0, sk, g, fs, b);
+            });
+            launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] { hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(256), ((size_t)g.nmb * 15 + 15) & ~(size_t)15, sk, g, fs, b); });
+            launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, sk, g, fs, b, 0, 6, 1); });
+        }
+        if (!any) break;
+    }
+    if (L > 1 && NG > 1)
+        for (int k = 1; k < NG; k++) { hipEventRecord(ctx->ev_pjoin[k], ctx->pstream[k]); hipStreamWaitEvent(st, ctx->ev_pjoin[k], 0); }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -390,7 +416,7 @@ const char* icsp_last_error(const icsp_ctx_t* ctx) { return ctx ? ctx->err.c_str
 
 const char* icsp_kernel_name(int k)
 {
-    static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial" };
+    static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack" };
     return (k >= 0 && k < ICSP_K_COUNT) ? names[k] : "?";
 }
 
@@ -421,7 +447,11 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->n_cu = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ctx->n_cu = v; }
     memset(&ctx->b, 0, sizeof(ctx->b));
+    memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0;
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
+    for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
+    ctx->p_groups = 2;                 // measured: 2 groups +7 %, 3 no better, more streams than hardware queues collapse
+    if (const char* v = getenv("ICSP_P_GROUPS")) { int k = atoi(v); if (k >= 1 && k <= kMaxPGroups) ctx->p_groups = k; }
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
     auto fail = [&](int code, const char* what, hipError_t e) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); icsp_destroy(ctx); return code; };
     hipError_t e;
@@ -432,6 +462,10 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if ((e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
+    for (int k = 1; k < ctx->p_groups; k++) {
+        if ((e = hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, prio_hi)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
+        if ((e = hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
+    }
     // k_frame_serial stages a frame's block sums, vectors and states in dynamic LDS: 15 bytes per macroblock
     if ((e = hipFuncSetAttribute((const void*)k_frame_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
@@ -468,14 +502,17 @@ int icsp_destroy(icsp_ctx_t* ctx)
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
+    for (int k = 1; k < kMaxPGroups; k++) if (ctx->pstream[k]) hipStreamSynchronize(ctx->pstream[k]);
     for (auto& e : ctx->ev_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : ctx->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     hipFree(ctx->d_frames); hipFree(ctx->b.recon); hipFree(ctx->b.levels); hipFree(ctx->b.acflag); hipFree(ctx->b.mpm);
     hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.me_sums); hipFree(ctx->b.me_flag);
     hipFree(ctx->b.dcpred); hipFree(ctx->b.coef);
+    hipFree(ctx->pk.unit_bits); hipFree(ctx->pk.unit_off); hipFree(ctx->pk.frame_bits); hipFree(ctx->pk.frame_base); hipFree(ctx->pk.out);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+    for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) hipEventDestroy(ctx->ev_pjoin[k]); if (ctx->pstream[k]) hipStreamDestroy(ctx->pstream[k]); }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return ICSP_OK;
@@ -521,6 +558,56 @@ int icsp_download(icsp_ctx_t* ctx, int first, int n, int16_t* levels, uint8_t* a
     if (recon) HIPCHK(hipMemcpyAsync(recon, ctx->b.recon + f * ctx->g.fsz, c * ctx->g.fsz, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (ctx->profiling) collect_profile(ctx);
+    return ICSP_OK;
+}
+
+int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap, uint64_t* nbits)
+{
+    if (!ctx || !body || !nbits) return ICSP_ERR_UNENOUGH_PARAM;
+    if (int rc = check_range(ctx, first, n)) return rc;
+    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
+    if (first % L != 0) return ICSP_ERR_RANGE;
+    *nbits = 0;
+    if (n == 0) return ICSP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const Geo& g = ctx->g;
+    if (!ctx->pk.out) {
+        const size_t units = (size_t)ctx->max_frames * g.nmb * 6;
+        ctx->pk_cap = (icsp_bitstream_bound(&ctx->p, ctx->max_frames) + 16 + 3) & ~(size_t)3;
+        hipError_t e = hipSuccess;
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.unit_bits, units * sizeof(uint16_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.unit_off, units * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.frame_bits, (size_t)ctx->max_frames * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.frame_base, ((size_t)ctx->max_frames + 1) * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.out, ctx->pk_cap);
+        if (e != hipSuccess) {
+            hipFree(ctx->pk.unit_bits); hipFree(ctx->pk.unit_off); hipFree(ctx->pk.frame_bits); hipFree(ctx->pk.frame_base); hipFree(ctx->pk.out);
+            memset(&ctx->pk, 0, sizeof(ctx->pk));
+            ctx->err = std::string("hipMalloc bit packer: ") + hipGetErrorString(e);
+            return ICSP_ERR_MEM_ALLOC;
+        }
+    }
+    hipStream_t st = ctx->stream;
+    const long long units = (long long)n * g.nmb * 6;
+    const DevBufs& b = ctx->b;
+    const PackBufs& pk = ctx->pk;
+    launch_timed(ctx, ICSP_K_PACK, st, [&] {
+        hipLaunchKernelGGL(k_bits_count, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, g, first, n, L, b, pk);
+        hipLaunchKernelGGL(k_bits_scan, dim3(n), dim3(256), 0, st, g, n, pk);
+        hipLaunchKernelGGL(k_frame_base, dim3(1), dim3(256), 0, st, n, pk);
+        hipLaunchKernelGGL(k_pack_zero, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, g, n, pk);
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, g, first, n, L, b, pk);
+    });
+    HIPCHK(hipGetLastError());
+    unsigned long long total = 0;
+    HIPCHK(hipMemcpyAsync(&total, pk.frame_base + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const size_t nbytes = (size_t)((total + 7) / 8);
+    if (nbytes > cap) return ICSP_ERR_RANGE;
+    if (nbytes) HIPCHK(hipMemcpyAsync(body, pk.out, nbytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (ctx->profiling) collect_profile(ctx);
+    *nbits = total;
     return ICSP_OK;
 }
 

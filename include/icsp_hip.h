@@ -94,7 +94,7 @@ int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
 
 /* ---- per-kernel timing with HIP events on the launch stream ---------------------------------- */
-enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_CHROMA_DC, ICSP_K_RESIDUAL, ICSP_K_ME, ICSP_K_FRAME_SERIAL, ICSP_K_COUNT };
+enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_CHROMA_DC, ICSP_K_RESIDUAL, ICSP_K_ME, ICSP_K_FRAME_SERIAL, ICSP_K_PACK, ICSP_K_COUNT };
 /* on: 0 = off, 1 = time every kernel, otherwise a mask with bit (k+1) set for each kernel k to time (events cost a few
  * microseconds per launch, so the bench times only the dominant kernel inside its timed region). */
 int icsp_profile_enable(icsp_ctx_t* ctx, int on);
@@ -111,6 +111,20 @@ size_t icsp_bitstream_bound(const icsp_params_t* params, int n);
 int icsp_write_bitstream(const icsp_params_t* params, int n,
                          const int16_t* levels, const uint8_t* acflag, const uint8_t* mpm_mode, const int8_t* mvd,
                          uint8_t* out, size_t cap, size_t* out_bytes);
+
+
+/* ---- device back end: the same body bits packed on the GPU ------------------------------------- */
+/* The value code is a fixed table (ENC:5417-5602), so bit lengths, prefix sums and packing parallelise per block.
+ * Packs the body (everything after the 14-byte header) of the already encoded slots [first, first+n), first GOP
+ * aligned, as an MSB-first bit string, copies its ceil(nbits/8) bytes (zero padded) to host memory `body` and writes the
+ * bit count to *nbits.  Only the bits cross PCIe instead of levels/flags/vectors (about 1/30 of the bytes at QP 16).
+ * cap >= icsp_bitstream_bound() - 14 always suffices; ICSP_ERR_RANGE if the body does not fit cap. */
+int icsp_pack_bits(icsp_ctx_t* ctx, int first_frame, int n, uint8_t* body, size_t cap, uint64_t* nbits);
+/* Host: header + the pieces (each an MSB-first bit string of piece_bits[i] bits, e.g. one per GPU shard, in frame
+ * order) concatenated bit-wise + the reference's final byte (its bits right-aligned, ENC:4956) -> the .bin image,
+ * identical to icsp_write_bitstream on the same frames.  *out_bytes = 14 + total_bits/8 + 1. */
+int icsp_bitstream_assemble(const icsp_params_t* params, int npieces, const uint8_t* const* pieces,
+                            const uint64_t* piece_bits, uint8_t* out, size_t cap, size_t* out_bytes);
 
 #ifdef __cplusplus
 }

@@ -220,3 +220,40 @@ def test_config4_all_twelve_clips_hashes(golden_dir):
         bs = capi.write_bitstream(W, H, 16, 16, 10, o["levels"], o["acflag"], o["mpm"], o["mvd"])
         assert len(bs) == s["bin_bytes"] and hashlib.sha256(bs).hexdigest() == s["bin_sha256"], s["clip"]
     enc.close()
+
+
+@pytest.mark.parametrize("name,n,q,period,w,h", [
+    ("foremanlike", 4, 16, 0, W, H), ("stefanlike", 7, 8, 3, W, H), ("mobilelike", 3, 1, 3, W, H),
+    ("staticlike", 4, 1, 4, W, H), ("akiyolike", 5, 16, 5, W, H), ("tablelike", 3, 8, 2, 64, 48), ("newslike", 2, 16, 2, 32, 16),
+])
+def test_device_bit_packer_equals_host_writer(name, n, q, period, w, h):
+    """icsp_pack_bits + icsp_bitstream_assemble == icsp_write_bitstream (itself byte-identical to the reference) — large
+    codes (QP 1), ACflag runs (static), P headers, a frame of two macroblocks (units of several frames in one wave)."""
+    clip = clipgen.synth_clip(name, n, width=w, height=h)
+    enc = capi.Encoder(w, h, q, q, period, max_frames=n)
+    o = enc.encode(clip)
+    want = capi.write_bitstream(w, h, q, q, period, o["levels"], o["acflag"], o["mpm"], o["mvd"])
+    got = enc.pack_bitstream(0, n)
+    assert len(got) == len(want)
+    assert got == want
+    L = period if period else 1
+    if n > L:                                           # a GOP-aligned sub-range, and shard pieces concatenated on the host
+        tail = enc.pack_bitstream(L, n - L)
+        s = slice(L, n)
+        assert tail == capi.write_bitstream(w, h, q, q, period, o["levels"][s], o["acflag"][s], o["mpm"][s], o["mvd"][s])
+        pieces = [enc.pack_bits(0, L), enc.pack_bits(L, n - L)]
+        assert capi.assemble_bitstream(w, h, q, q, period, pieces) == want
+    enc.close()
+
+
+def test_device_bit_packer_full_baseline_hash(golden_dir):
+    """BASELINE configs[2] (stefanlike 300 f, --intraPeriod 10, QP 8): device-packed .bin SHA-256 == the reference CLI's."""
+    streams = json.load(open(os.path.join(golden_dir, "streams.json")))
+    s = next(x for x in streams if (x["clip"], x["nframes"], x["qp"], x["intra_period"]) == ("stefanlike", 300, 8, 10))
+    clip = clipgen.synth_clip("stefanlike", 300)
+    enc = capi.Encoder(W, H, 8, 8, 10, max_frames=300)
+    enc.upload(clip, 0)
+    enc.encode_resident(0, 300)
+    bs = enc.pack_bitstream(0, 300)
+    enc.close()
+    assert len(bs) == s["bin_bytes"] and hashlib.sha256(bs).hexdigest() == s["bin_sha256"]

@@ -97,3 +97,39 @@ def test_create_without_device_fails_loudly_not_silently():
         pytest.skip("GPU present")
     with pytest.raises(capi.IcspError, match="no usable HIP device"):
         capi.Encoder(W, H, 16, 16, 0, max_frames=1)
+
+
+def body_bits(levels, acflag, mvd, period):
+    """Bit count of the stream body from the syntax (ENC:4923-5236) and the value code's lengths (ENC:5417-5602)."""
+    def vlen(v):
+        a = np.abs(v.astype(np.int64))
+        e = np.floor(np.log2(np.maximum(a, 1))).astype(np.int64)
+        return np.where(a == 0, 2, np.where(a == 1, 4, np.where(a <= 31, 4 + e, 2 * np.minimum(e, 11))))
+    n = levels.shape[0]
+    intra = np.array([period == 0 or f % period == 0 for f in range(n)])
+    dc = vlen(levels[..., 0]) + 1
+    ac = np.where(acflag == 1, 63, vlen(levels[..., 1:]).sum(-1))
+    total = int((dc + ac).sum())
+    total += int(intra.sum()) * levels.shape[1] * 8                                  # 4 x (MPMFlag + intraPredMode)
+    total += int((1 + vlen(mvd[~intra]).sum(-1)).sum())                              # mode flag + mvd x, y
+    return total
+
+
+def test_assemble_pieces_equals_one_pass_writer():
+    """icsp_bitstream_assemble: per-GOP bodies concatenated bit-wise == the sequential writer on the whole sequence."""
+    W, H, q, period, n = 64, 48, 8, 3, 8                                             # GOPs of 3, 3, 2 frames
+    clip = clipgen.synth_clip("stefanlike", n, width=W, height=H)
+    o = po.encode_sequence(clip, W, H, q, q, period)
+    whole = capi.write_bitstream(W, H, q, q, period, o["levels"], o["acflag"], o["mpm"], o["mvd"])
+    pieces = []
+    for g0 in range(0, n, period):
+        s = slice(g0, min(g0 + period, n))
+        nb = body_bits(o["levels"][s], o["acflag"][s], o["mvd"][s], period)
+        b = bytearray(capi.write_bitstream(W, H, q, q, period, o["levels"][s], o["acflag"][s], o["mpm"][s], o["mvd"][s])[14:])
+        assert len(b) == nb // 8 + 1
+        if nb % 8:
+            b[-1] = (b[-1] << (8 - nb % 8)) & 0xff                                   # undo the right-aligned final byte
+        pieces.append((bytes(b[: (nb + 7) // 8]), nb))
+    assert sum(nb for _, nb in pieces) // 8 + 1 + 14 == len(whole)
+    assert capi.assemble_bitstream(W, H, q, q, period, pieces) == whole
+    assert capi.assemble_bitstream(W, H, q, q, period, []) == whole[:14] + b"\x00"
