@@ -152,6 +152,21 @@ def main():
     t0 = time.perf_counter()
     enc.encode(clip)
     pcie_dt = time.perf_counter() - t0
+    # the same with the body packed on the device, so that only the bits come back (icsp_pack_bits)
+    hostbuf = np.empty(64 << 20, np.uint8)
+    enc.pack_bits(0, NFRAMES, hostbuf)
+    enc.profile(True, only=["k_pack"])
+    t0 = time.perf_counter()
+    enc.upload(clip)
+    enc.encode_resident(0, NFRAMES)
+    body, nbits = enc.pack_bits(0, NFRAMES, hostbuf)
+    e2e_dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(3):
+        enc.pack_bits(0, NFRAMES, hostbuf)
+    pack_dt = (time.perf_counter() - t0) / 3
+    pack_ms = enc.profile_get()["k_pack"]
+    enc.profile(False)
     enc.close()
     fps = world * NFRAMES * a.steps / dt
     kern_ms = ms_ai / max(n_ai, 1)
@@ -198,6 +213,10 @@ def main():
         "kernels_ms_per_step": {k: round(v[0], 4) for k, v in prof.items() if v[1]},
         "psnr_y_db": round(psnr_ai, 4),
         "pcie_inclusive_fps": round(NFRAMES / pcie_dt, 1),
+        "device_pack": {"bin_bytes": 14 + nbits // 8 + 1, "kernels_ms": round(pack_ms[0] / max(pack_ms[1], 1), 4),
+                        "pack_and_copy_ms": round(pack_dt * 1e3, 3), "upload_encode_pack_fps": round(NFRAMES / e2e_dt, 1),
+                        "note": "5 kernels (count, 2 scans, zero, pack) + D2H of the bits only; pcie_inclusive_fps copies "
+                                "levels/flags/vectors/recon back instead"},
         "ippp": {"workload": "stefanlike_cif 300f, --intraPeriod 10, QP=8 (BASELINE configs[2])", "value": round(fps2, 1),
                  "unit": "frames/s", "ms_per_step": round(dt2 / steps2 * 1e3, 4), "psnr_y_db": round(psnr_ip, 4),
                  "read_roofline_frac": round(fps2 / world * read_mean_ip / 1e9 / HBM_PEAK_GBS, 5),

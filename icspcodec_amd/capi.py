@@ -184,13 +184,14 @@ class Encoder:
     def keep_coef(self, on=True):
         self._chk(self.lib.icsp_debug_keep_coef(self.ctx, int(on)), "icsp_debug_keep_coef")
 
-    def pack_bits(self, first, n):
-        """Device bit packer on the encoded slots [first, first+n): (body bytes as uint8 array, bit count)."""
-        cap = self.lib.icsp_bitstream_bound(C.byref(self.params), n)
-        body = np.zeros(cap, np.uint8)
+    def pack_bits(self, first, n, out=None):
+        """Device bit packer on the encoded slots [first, first+n): (body bytes as uint8 array, bit count).
+        `out`: optional reusable uint8 host buffer (icsp_bitstream_bound bytes always suffice)."""
+        if out is None:
+            out = np.empty(self.lib.icsp_bitstream_bound(C.byref(self.params), n), np.uint8)
         nbits = C.c_uint64(0)
-        self._chk(self.lib.icsp_pack_bits(self.ctx, first, n, _vp(body), cap, C.byref(nbits)), "icsp_pack_bits")
-        return body[: (nbits.value + 7) // 8], nbits.value
+        self._chk(self.lib.icsp_pack_bits(self.ctx, first, n, _vp(out), out.size, C.byref(nbits)), "icsp_pack_bits")
+        return out[: (nbits.value + 7) // 8], nbits.value
 
     def pack_bitstream(self, first, n) -> bytes:
         """The .bin image of slots [first, first+n) with the body packed on the device."""

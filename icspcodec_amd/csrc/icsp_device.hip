@@ -508,7 +508,7 @@ int icsp_destroy(icsp_ctx_t* ctx)
     hipFree(ctx->d_frames); hipFree(ctx->b.recon); hipFree(ctx->b.levels); hipFree(ctx->b.acflag); hipFree(ctx->b.mpm);
     hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.me_sums); hipFree(ctx->b.me_flag);
     hipFree(ctx->b.dcpred); hipFree(ctx->b.coef);
-    hipFree(ctx->pk.unit_bits); hipFree(ctx->pk.unit_off); hipFree(ctx->pk.frame_bits); hipFree(ctx->pk.frame_base); hipFree(ctx->pk.out);
+    hipFree(ctx->pk.grp_bits); hipFree(ctx->pk.grp_off); hipFree(ctx->pk.chunk_bits); hipFree(ctx->pk.chunk_base); hipFree(ctx->pk.out);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
@@ -571,36 +571,38 @@ int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap,
     if (n == 0) return ICSP_OK;
     HIPCHK(hipSetDevice(ctx->device));
     const Geo& g = ctx->g;
+    const long long cap_grps = ((long long)ctx->max_frames * g.nmb * 6 + kGrpUnits - 1) / kGrpUnits;
     if (!ctx->pk.out) {
-        const size_t units = (size_t)ctx->max_frames * g.nmb * 6;
+        const size_t chunks = (size_t)((cap_grps + kChunkGrps - 1) / kChunkGrps);
         ctx->pk_cap = (icsp_bitstream_bound(&ctx->p, ctx->max_frames) + 16 + 3) & ~(size_t)3;
         hipError_t e = hipSuccess;
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.unit_bits, units * sizeof(uint16_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.unit_off, units * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.frame_bits, (size_t)ctx->max_frames * 8);
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.frame_base, ((size_t)ctx->max_frames + 1) * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.grp_bits, (size_t)cap_grps * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.grp_off, (size_t)cap_grps * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.chunk_bits, chunks * 8);
+        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.chunk_base, (chunks + 1) * 8);
         if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.out, ctx->pk_cap);
         if (e != hipSuccess) {
-            hipFree(ctx->pk.unit_bits); hipFree(ctx->pk.unit_off); hipFree(ctx->pk.frame_bits); hipFree(ctx->pk.frame_base); hipFree(ctx->pk.out);
+            hipFree(ctx->pk.grp_bits); hipFree(ctx->pk.grp_off); hipFree(ctx->pk.chunk_bits); hipFree(ctx->pk.chunk_base); hipFree(ctx->pk.out);
             memset(&ctx->pk, 0, sizeof(ctx->pk));
             ctx->err = std::string("hipMalloc bit packer: ") + hipGetErrorString(e);
             return ICSP_ERR_MEM_ALLOC;
         }
     }
     hipStream_t st = ctx->stream;
-    const long long units = (long long)n * g.nmb * 6;
+    const long long ngrp = ((long long)n * g.nmb * 6 + kGrpUnits - 1) / kGrpUnits;
+    const int nchunk = (int)((ngrp + kChunkGrps - 1) / kChunkGrps);
     const DevBufs& b = ctx->b;
     const PackBufs& pk = ctx->pk;
     launch_timed(ctx, ICSP_K_PACK, st, [&] {
-        hipLaunchKernelGGL(k_bits_count, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, g, first, n, L, b, pk);
-        hipLaunchKernelGGL(k_bits_scan, dim3(n), dim3(256), 0, st, g, n, pk);
-        hipLaunchKernelGGL(k_frame_base, dim3(1), dim3(256), 0, st, n, pk);
-        hipLaunchKernelGGL(k_pack_zero, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, g, n, pk);
-        hipLaunchKernelGGL(k_pack, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, st, g, first, n, L, b, pk);
+        hipLaunchKernelGGL(k_bits_count, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, g, first, n, L, ngrp, b, pk);
+        hipLaunchKernelGGL(k_bits_scan, dim3(nchunk), dim3(256), 0, st, ngrp, pk);
+        hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(256), 0, st, nchunk, pk);
+        hipLaunchKernelGGL(k_pack_zero, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, st, ngrp, pk);
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, g, first, n, L, ngrp, b, pk);
     });
     HIPCHK(hipGetLastError());
     unsigned long long total = 0;
-    HIPCHK(hipMemcpyAsync(&total, pk.frame_base + n, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&total, pk.chunk_base + nchunk, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     const size_t nbytes = (size_t)((total + 7) / 8);
     if (nbytes > cap) return ICSP_ERR_RANGE;

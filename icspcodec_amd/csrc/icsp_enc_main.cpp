@@ -8,9 +8,11 @@
 //   multi_thread_encoding     ENC:179-213, ICSP_thread.cpp:39-77   closed-GOP job queue -> here: closed-GOP shards, one host thread per GPU
 //   makebitstream             ENC:4849-4900             <prefix>_compCIF_<QDC>_<QAC>_<period>.bin
 //   checkResultFrames         ENC:6376-6421             test_yuv.yuv (reconstruction) in the working directory
-// What runs on the GPU is everything between loading the frames and packing the bits (include/icsp_hip.h).
+// What runs on the GPU is everything between loading the frames and writing the files, bit packing included
+// (include/icsp_hip.h); the host concatenates the per-device bit strings and adds the header.
 //
 // Extensions use long options the reference rejects as unknown, so its own surface is unchanged:
+//   --hostpack      sequential bit writer on the host instead of the device packer (same bytes; for cross-checks)
 //   --gpus N        shard closed GOPs over N devices (default 1; --EnMultiThread N means the same here, N host threads = N GPUs)
 //   --width W --height H   frame size (the reference hard-codes 352x288, encoder_main.cpp:20)
 // Deliberate differences: the thread-pool mode also writes the .bin (the reference commented that call out,
@@ -32,7 +34,7 @@ enum { SUCCESS = 0, UNENOUGH_PARAM, UNCORRECT_PARAM, FAIL_MEM_ALLOC };
 struct Options {
     char yuv_fname[256];
     int total_frames, qp_dc, qp_ac, intra_period, multi_thread_mode, nthreads;
-    int gpus, width, height;
+    int gpus, width, height, hostpack;
 };
 
 void print_help_message()
@@ -50,6 +52,7 @@ void print_help_message()
     printf("--intraPeriod: period of intra frame(0: All intra)\n");
     printf("--EnMultiThread: enable multi threading mode, also the number of thread(0~4, 0 is disable)\n");
     printf("--gpus : [MI355X build] number of GPUs to shard closed GOPs over (default 1)\n");
+    printf("--hostpack : [MI355X build] pack the bitstream on the host instead of on the device (same bytes)\n");
     printf("--width, --height : [MI355X build] frame size, multiples of 16 (default 352x288)\n");
 }
 
@@ -83,6 +86,7 @@ int parsing_command(int argc, char* argv[], Options* cmd)
             else if (!strcmp(name, "gpus")) cmd->gpus = atoi(val);
             else if (!strcmp(name, "width")) cmd->width = atoi(val);
             else if (!strcmp(name, "height")) cmd->height = atoi(val);
+            else if (!strcmp(name, "hostpack")) cmd->hostpack = 1;
             else return UNCORRECT_PARAM;
         } else {
             if (o[1] == 'i') { strncpy(cmd->yuv_fname, val, 255); cmd->yuv_fname[255] = 0; }
@@ -95,7 +99,7 @@ int parsing_command(int argc, char* argv[], Options* cmd)
     return SUCCESS;
 }
 
-struct Shard { int device, first, count, rc; std::string err; };
+struct Shard { int device, first, count, rc; std::string err; std::vector<uint8_t> body; uint64_t bits; };
 
 } // namespace
 
@@ -125,10 +129,6 @@ int main(int argc, char* argv[])
     fclose(fp);
     if ((int)got != n) { printf("fail to load cif.yuv\n error from YCbCrLoad\n"); exit(-1); }
 
-    std::vector<int16_t> levels(nmb * 384 * n);
-    std::vector<uint8_t> acflag(nmb * 6 * n), mpm(nmb * 4 * n), recon(fsz * n);
-    std::vector<int8_t> mvd(nmb * 2 * n);
-
     // closed-GOP shards, one host thread + one context per GPU (the analogue of encoding_thread, ENC:186-213)
     int ngpu = opt.gpus > 0 ? opt.gpus : (opt.multi_thread_mode > 0 ? opt.nthreads : 1);
     const int L = opt.intra_period > 0 ? opt.intra_period : 1;
@@ -140,17 +140,32 @@ int main(int argc, char* argv[])
         int gcount = ngop / ngpu + (d < ngop % ngpu ? 1 : 0);
         shards[d].device = d; shards[d].first = g0 * L;
         shards[d].count = std::min(n, (g0 + gcount) * L) - g0 * L;
-        shards[d].rc = 0;
+        shards[d].rc = 0; shards[d].bits = 0;
         g0 += gcount;
     }
     icsp_params_t params{ W, H, opt.qp_dc, opt.qp_ac, opt.intra_period };
+    std::vector<uint8_t> recon(fsz * n);
+    // --hostpack: bring levels/flags/vectors back and run the sequential writer on the host (the round-1 path, kept for
+    // cross-checking).  Default: each device packs the bits of its shard, only bits + reconstruction cross PCIe.
+    std::vector<int16_t> levels;
+    std::vector<uint8_t> acflag, mpm;
+    std::vector<int8_t> mvd;
+    if (opt.hostpack) { levels.resize(nmb * 384 * n); acflag.resize(nmb * 6 * n); mpm.resize(nmb * 4 * n); mvd.resize(nmb * 2 * n); }
     auto work = [&](Shard* s) {
         icsp_ctx_t* ctx = nullptr;
         s->rc = icsp_create(&ctx, &params, s->device, s->count);
         if (s->rc) { s->err = icsp_strerror(s->rc); return; }
         const size_t f = s->first;
-        s->rc = icsp_encode_gop(ctx, yuv.data() + f * fsz, s->count, levels.data() + f * nmb * 384, acflag.data() + f * nmb * 6,
-                                mpm.data() + f * nmb * 4, mvd.data() + f * nmb * 2, recon.data() + f * fsz);
+        if (opt.hostpack) {
+            s->rc = icsp_encode_gop(ctx, yuv.data() + f * fsz, s->count, levels.data() + f * nmb * 384, acflag.data() + f * nmb * 6,
+                                    mpm.data() + f * nmb * 4, mvd.data() + f * nmb * 2, recon.data() + f * fsz);
+        } else {
+            s->body.resize(icsp_bitstream_bound(&params, s->count));
+            s->rc = icsp_upload(ctx, yuv.data() + f * fsz, 0, s->count);
+            if (!s->rc) s->rc = icsp_encode_resident(ctx, 0, s->count);
+            if (!s->rc) s->rc = icsp_pack_bits(ctx, 0, s->count, s->body.data(), s->body.size(), &s->bits);
+            if (!s->rc) s->rc = icsp_download(ctx, 0, s->count, nullptr, nullptr, nullptr, nullptr, recon.data() + f * fsz);
+        }
         if (s->rc) s->err = std::string(icsp_strerror(s->rc)) + ": " + icsp_last_error(ctx);
         icsp_destroy(ctx);
     };
@@ -165,9 +180,17 @@ int main(int argc, char* argv[])
         printf("Encoding FRAME_%03d(%c) done!\n", f, (opt.intra_period == 0 || f % opt.intra_period == 0) ? 'I' : 'P');
 
     // makebitstream (ENC:4849-4900)
-    size_t cap = icsp_bitstream_bound(&params, n), nbytes = 0;
+    size_t cap = icsp_bitstream_bound(&params, n) + 2, nbytes = 0;
     std::vector<uint8_t> bs(cap);
-    int rc = icsp_write_bitstream(&params, n, levels.data(), acflag.data(), mpm.data(), mvd.data(), bs.data(), cap, &nbytes);
+    int rc;
+    if (opt.hostpack) {
+        rc = icsp_write_bitstream(&params, n, levels.data(), acflag.data(), mpm.data(), mvd.data(), bs.data(), cap, &nbytes);
+    } else {
+        std::vector<const uint8_t*> pieces;
+        std::vector<uint64_t> pbits;
+        for (auto& s : shards) { pieces.push_back(s.body.data()); pbits.push_back(s.bits); }
+        rc = icsp_bitstream_assemble(&params, (int)pieces.size(), pieces.data(), pbits.data(), bs.data(), cap, &nbytes);
+    }
     if (rc) { printf("[ERROR] %s in makebitstream\n", icsp_strerror(rc)); exit(-1); }
     char name[512];
     snprintf(name, sizeof(name), "%s_compCIF_%d_%d_%d.bin", prefix.c_str(), opt.qp_dc, opt.qp_ac, opt.intra_period);

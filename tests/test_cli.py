@@ -35,7 +35,8 @@ def test_option_errors_match_reference_messages_and_exit_code(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("period,extra", [(6, []), (0, []), (1, []), (6, ["--EnMultiThread", "1"])])
+@pytest.mark.parametrize("period,extra", [(6, []), (0, []), (1, []), (6, ["--EnMultiThread", "1"]), (6, ["--hostpack"]),
+                                          (0, ["--hostpack"])])
 def test_cli_outputs_equal_reference_files(tmp_path, golden_dir, period, extra):
     n, qp = 12, 16
     clip = clipgen.synth_clip("foremanlike", n)
