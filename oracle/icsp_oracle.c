@@ -12,6 +12,7 @@
  * ENC = /root/reference/source/encoder/ICSP_Codec_Encoder_source.cpp
  */
 #include "icsp_oracle.h"
+#include "icsp_oracle_internal.h"
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
@@ -108,7 +109,7 @@ void icsp_oracle_zigzag(const int in[64], int out[64])
     for (int k = 0; k < 64; k++) out[k] = in[g_zz[k]];
 }
 
-static int median3(int a, int b, int c)   /* ENC:3677-3679 and every other median site */
+int icspo_median3(int a, int b, int c)   /* ENC:3677-3679 and every other median site */
 {
     if ((a > b) && (a > c)) return (b > c) ? b : c;
     else if ((b > a) && (b > c)) return (a > c) ? a : c;
@@ -233,24 +234,24 @@ static int transform_chain(const int err[64], int dcpred, int qdc, int qac, int 
  * Restated from the four macroblock-position cases: frame's first block 1024; first block row L;
  * first block column U; blk3 of any MB and blk1 of the last MB column median(L,UL,U); everything
  * else median(L,U,UR).  rec is the reconstructed-DC grid [rows8][cols8]. */
-static int luma_dcpred(const int* rec, int r8, int c8, int cols8)
+int icspo_luma_dcpred(const int* rec, int r8, int c8, int cols8)
 {
     if (r8 == 0 && c8 == 0) return 1024;
     if (r8 == 0) return rec[c8 - 1];
     if (c8 == 0) return rec[(r8 - 1) * cols8];
     int L = rec[r8 * cols8 + c8 - 1], U = rec[(r8 - 1) * cols8 + c8];
-    if (((r8 & 1) && (c8 & 1)) || c8 == cols8 - 1) return median3(L, rec[(r8 - 1) * cols8 + c8 - 1], U);
-    return median3(L, U, rec[(r8 - 1) * cols8 + c8 + 1]);
+    if (((r8 & 1) && (c8 & 1)) || c8 == cols8 - 1) return icspo_median3(L, rec[(r8 - 1) * cols8 + c8 - 1], U);
+    return icspo_median3(L, U, rec[(r8 - 1) * cols8 + c8 + 1]);
 }
 
 /* DC predictor on the chroma block grid (ENC:4482-4513). */
-static int chroma_dcpred(const int* rec, int n, int sw)
+int icspo_chroma_dcpred(const int* rec, int n, int sw)
 {
     if (n == 0) return 1024;
     if (n / sw == 0) return rec[n - 1];
     if (n % sw == 0) return rec[n - sw];
-    if (n % sw == sw - 1) return median3(rec[n - 1], rec[n - sw - 1], rec[n - sw]);
-    return median3(rec[n - 1], rec[n - sw], rec[n - sw + 1]);
+    if (n % sw == sw - 1) return icspo_median3(rec[n - 1], rec[n - sw - 1], rec[n - sw]);
+    return icspo_median3(rec[n - 1], rec[n - sw], rec[n - sw + 1]);
 }
 
 static uint8_t clip255(int t) { t = (t > 255) ? 255 : t; t = (t < 0) ? 0 : t; return (uint8_t)t; }
@@ -313,7 +314,7 @@ void icsp_oracle_intra_frame(const uint8_t* frame, int w, int h, int qdc, int qa
                 int p;
                 if (!upav)      p = mode[r8 * cols8 + c8 - 1];
                 else if (!leav) p = mode[(r8 - 1) * cols8 + c8];
-                else p = median3(mode[r8 * cols8 + c8 - 1], mode[(r8 - 1) * cols8 + c8 - 1], mode[(r8 - 1) * cols8 + c8]);
+                else p = icspo_median3(mode[r8 * cols8 + c8 - 1], mode[(r8 - 1) * cols8 + c8 - 1], mode[(r8 - 1) * cols8 + c8]);
                 mpm = (m == p);
                 if (!mpm) {
                     if (p == 0)      ipm = (m == 1) ? 0 : 1;
@@ -324,7 +325,7 @@ void icsp_oracle_intra_frame(const uint8_t* frame, int w, int h, int qdc, int qa
             mpm_mode[n * 4 + k] = (uint8_t)(mpm | (ipm << 1));
             const int* err = (m == 0) ? e0 : (m == 1) ? e1 : e2;
             double idct[64];
-            int pred = luma_dcpred(recdc, r8, c8, cols8);
+            int pred = icspo_luma_dcpred(recdc, r8, c8, cols8);
             recdc[r8 * cols8 + c8] = transform_chain(err, pred, qdc, qac, 0, levels + (n * 6 + k) * 64,
                                                      acflag + n * 6 + k, idct,
                                                      dbg_coef ? dbg_coef + (n * 6 + k) * 64 : 0);
@@ -347,7 +348,7 @@ void icsp_oracle_intra_frame(const uint8_t* frame, int w, int h, int qdc, int qa
             int err[64];
             for (int y = 0; y < 8; y++) for (int x = 0; x < 8; x++) err[y * 8 + x] = src[y * cw + x];
             double idct[64];
-            int pred = chroma_dcpred(crec[pl], n, sw);
+            int pred = icspo_chroma_dcpred(crec[pl], n, sw);
             crec[pl][n] = transform_chain(err, pred, qdc, qac, 1, levels + (n * 6 + 4 + pl) * 64,
                                           acflag + n * 6 + 4 + pl, idct,
                                           dbg_coef ? dbg_coef + (n * 6 + 4 + pl) * 64 : 0);
@@ -366,7 +367,7 @@ void icsp_oracle_intra_frame(const uint8_t* frame, int w, int h, int qdc, int qa
 /* MV predictor (ENC:2353-2425): 8 for MB 0, left on row 0, up on column 0, else a median of
  * (L,UL,U) on the last column or (L,U,UR) elsewhere.  The y component carries the reference's
  * `(y1>x3)` typo (ENC:2399, 2418) and is therefore not always a median. */
-static void mv_pred(const int* mx, const int* my, int n, int sw, int* px, int* py)
+void icspo_mv_pred(const int* mx, const int* my, int n, int sw, int* px, int* py)
 {
     if (n == 0) { *px = 8; *py = 8; return; }
     if (n / sw == 0) { *px = mx[n - 1]; *py = my[n - 1]; return; }
@@ -374,7 +375,7 @@ static void mv_pred(const int* mx, const int* my, int n, int sw, int* px, int* p
     int i1 = n - 1, i2, i3;
     if (n % sw == sw - 1) { i2 = n - sw - 1; i3 = n - sw; } else { i2 = n - sw; i3 = n - sw + 1; }
     int x1 = mx[i1], x2 = mx[i2], x3 = mx[i3], y1 = my[i1], y2 = my[i2], y3 = my[i3];
-    *px = median3(x1, x2, x3);
+    *px = icspo_median3(x1, x2, x3);
     if ((y1 > y2) && (y1 > y3))      *py = (y2 > y3) ? y2 : y3;
     else if ((y2 > y1) && (y2 > y3)) *py = (y1 > x3) ? y1 : y3;
     else                              *py = (y1 > y2) ? y1 : y2;
@@ -404,7 +405,7 @@ void icsp_oracle_inter_frame(const uint8_t* frame, const uint8_t* prev, int w, i
         /* motionCompensation uses the raw mv (ENC:2185-2186); mvPrediction then replaces bd.mv by the
          * difference (ENC:2353) and ImvPrediction restores Reconstructedmv == raw mv (ENC:2426). */
         int px, py;
-        mv_pred(mx, my, n, sw, &px, &py);
+        icspo_mv_pred(mx, my, n, sw, &px, &py);
         mvd[n * 2 + 0] = (int8_t)(mx[n] - px);
         mvd[n * 2 + 1] = (int8_t)(my[n] - py);
         if (dbg_mv) { dbg_mv[n * 2] = (int8_t)mx[n]; dbg_mv[n * 2 + 1] = (int8_t)my[n]; }
@@ -418,7 +419,7 @@ void icsp_oracle_inter_frame(const uint8_t* frame, const uint8_t* prev, int w, i
                     err[y * 8 + x] = (int)Y[(R * 16 + oy + y) * w + C * 16 + ox + x]
                                    - (int)pad[(refy + oy + y) * pw + refx + ox + x];    /* ENC:2194 */
             double idct[64];
-            int pred = luma_dcpred(recdc, r8, c8, cols8);
+            int pred = icspo_luma_dcpred(recdc, r8, c8, cols8);
             recdc[r8 * cols8 + c8] = transform_chain(err, pred, qdc, qac, 0, levels + (n * 6 + k) * 64,
                                                      acflag + n * 6 + k, idct,
                                                      dbg_coef ? dbg_coef + (n * 6 + k) * 64 : 0);
@@ -452,7 +453,7 @@ void icsp_oracle_inter_frame(const uint8_t* frame, const uint8_t* prev, int w, i
                 for (int x = 0; x < 8; x++)
                     err[y * 8 + x] = (int)src[(R * 8 + y) * cw + C * 8 + x] - (int)cpad[(refy + y) * cpw + refx + x];
             double idct[64];
-            int pred = chroma_dcpred(crec, n, sw);
+            int pred = icspo_chroma_dcpred(crec, n, sw);
             crec[n] = transform_chain(err, pred, qdc, qac, 1, levels + (n * 6 + 4 + pl) * 64,
                                       acflag + n * 6 + 4 + pl, idct,
                                       dbg_coef ? dbg_coef + (n * 6 + 4 + pl) * 64 : 0);

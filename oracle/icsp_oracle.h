@@ -25,6 +25,7 @@
  */
 #ifndef ICSP_ORACLE_H
 #define ICSP_ORACLE_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -67,6 +68,22 @@ int icsp_oracle_encode_sequence(const uint8_t* yuv, int nframes, int w, int h,
                                 int qp_dc, int qp_ac, int intra_period, int nthreads,
                                 int16_t* levels, uint8_t* acflag, uint8_t* mpm_mode, int8_t* mvd,
                                 uint8_t* recon);
+
+/* ---- decoder restatement (icsp_oracle_dec.c; DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp) ---- */
+void icsp_oracle_dec_costable(double out[64]);                   /* DEC.h:19-27: double literals, unlike the encoder's floats */
+void icsp_oracle_dec_idct8x8(const int in[64], double out[64]);  /* DEC:3331-3445 (== CIDCT DEC:4220-4300) */
+int icsp_oracle_parse_header(const uint8_t* bin, size_t nbytes, int* w, int* h, int* qdc, int* qac, int* period);   /* DEC:14-37 */
+/* readBlockData (DEC:38-405): the .bin image -> the encoder-side arrays for nframes frames.  0, or -1 on a short stream. */
+int icsp_oracle_parse(const uint8_t* bin, size_t nbytes, int nframes,
+                      int16_t* levels, uint8_t* acflag, uint8_t* mpm_mode, int8_t* mvd);
+void icsp_oracle_decode_intra(const int16_t* levels, const uint8_t* mpm_mode, int w, int h, int qp_dc, int qp_ac,
+                              uint8_t* out);                                               /* DEC:2154-2219 */
+void icsp_oracle_decode_inter(const int16_t* levels, const int8_t* mvd, const uint8_t* prev_decoded, int w, int h,
+                              int qp_dc, int qp_ac, uint8_t* out, int8_t* dbg_mv);         /* DEC:2220-2272 */
+/* IcspCodec::decoding (DEC.h:286-312); intra_period <= 1 => every frame I.  out = [nframes][W*H*3/2] = check_test_*_yuv.yuv */
+int icsp_oracle_decode_sequence(const int16_t* levels, const uint8_t* mpm_mode, const int8_t* mvd, int nframes,
+                                int w, int h, int qp_dc, int qp_ac, int intra_period, uint8_t* out);
+double icsp_oracle_psnr_y(const uint8_t* orig, const uint8_t* dec, int nframes, int w, int h);   /* DEC.h:331-352 */
 
 #ifdef __cplusplus
 }

@@ -223,3 +223,77 @@ def run_ref_encoder(yuv_path, nframes, qp, intra_period, threads=0, cwd=None, qp
     if threads:
         cmd += ["--EnMultiThread", str(threads)]
     return subprocess.run(cmd, cwd=cwd or os.path.dirname(yuv_path), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+
+
+# ------------------------------------------------------------------ decoder restatement (icsp_oracle_dec.c)
+def parse_header(bs: bytes):
+    """(w, h, qdc, qac, period) of a .bin image (DEC:14-37)."""
+    b = np.frombuffer(bs, np.uint8)
+    v = [C.c_int(0) for _ in range(5)]
+    L = lib()
+    L.icsp_oracle_parse_header.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_int)] * 5
+    if L.icsp_oracle_parse_header(_vp(b), b.size, *[C.byref(x) for x in v]):
+        raise ValueError("not an ICSP stream")
+    return tuple(x.value for x in v)
+
+
+def parse_bitstream(bs: bytes, nframes: int):
+    """readBlockData (DEC:38-405): the .bin image -> dict(levels, acflag, mpm, mvd) + header fields."""
+    w, h, qdc, qac, period = parse_header(bs)
+    b = np.frombuffer(bs, np.uint8)
+    o = _alloc(nframes, w, h)
+    del o["recon"]
+    L = lib()
+    L.icsp_oracle_parse.argtypes = [C.c_void_p, C.c_size_t, C.c_int] + [C.c_void_p] * 4
+    if L.icsp_oracle_parse(_vp(b), b.size, nframes, _vp(o["levels"]), _vp(o["acflag"]), _vp(o["mpm"]), _vp(o["mvd"])):
+        raise ValueError("stream ends early")
+    o.update(width=w, height=h, qdc=qdc, qac=qac, period=period)
+    return o
+
+
+def decode_sequence(levels, mpm, mvd, w, h, qdc, qac, period):
+    """IcspCodec::decoding (DEC.h:286-312) on parsed arrays -> uint8 [n][W*H*3/2] (what check_test_*_yuv.yuv holds)."""
+    lv = _c(levels, np.int16); mp = _c(mpm, np.uint8); mv = _c(mvd, np.int8)
+    n = lv.shape[0]
+    out = np.zeros((n, w * h * 3 // 2), np.uint8)
+    lib().icsp_oracle_decode_sequence(_vp(lv), _vp(mp), _vp(mv), n, w, h, qdc, qac, period, _vp(out))
+    return out
+
+
+def decode_bitstream(bs: bytes, nframes: int):
+    p = parse_bitstream(bs, nframes)
+    return decode_sequence(p["levels"], p["mpm"], p["mvd"], p["width"], p["height"], p["qdc"], p["qac"], p["period"])
+
+
+def dec_idct8x8(blk):
+    b = _c(np.asarray(blk).reshape(64), np.int32)
+    out = np.zeros(64, np.float64)
+    lib().icsp_oracle_dec_idct8x8(_vp(b), _vp(out))
+    return out.reshape(8, 8)
+
+
+def psnr_y(orig, dec, w, h):
+    a = _c(orig, np.uint8); d = _c(dec, np.uint8)
+    L = lib()
+    L.icsp_oracle_psnr_y.restype = C.c_double
+    return L.icsp_oracle_psnr_y(_vp(a), _vp(d), a.shape[0], w, h)
+
+
+def run_ref_decoder(bs: bytes, clip, nframes, qdc, qac, period, workdir):
+    """Run the reference decoder binary (oracle/_ref/icsp_ref_dec) on a .bin image.  Returns (decoded uint8 [n][fsz], psnr).
+    It opens files literally named output\\<bin> and data\\<yuv> in its working directory (DEC.h:241, 323)."""
+    import glob
+    import re
+    binname, yuvname = "t_compCIF.bin", "t_cif.yuv"
+    open(os.path.join(workdir, "output\\" + binname), "wb").write(bs)
+    np.asarray(clip, np.uint8).tofile(os.path.join(workdir, "data\\" + yuvname))
+    for f in glob.glob(os.path.join(workdir, "check_test_*")) + glob.glob(os.path.join(workdir, "experimental_Result_Decoding.txt")):
+        os.remove(f)
+    r = subprocess.run([REF_DEC, str(nframes), binname, str(qdc), str(qac), str(period), yuvname], cwd=workdir,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout.decode(errors="replace"))
+    out = glob.glob(os.path.join(workdir, "check_test_*yuv.yuv"))
+    dec = np.fromfile(out[0], np.uint8).reshape(nframes, -1)
+    line = open(os.path.join(workdir, "experimental_Result_Decoding.txt")).read()
+    return dec, float(re.search(r"PSNR: ([0-9.]+)", line).group(1))
