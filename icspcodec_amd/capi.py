@@ -20,8 +20,9 @@ SYMBOLS = [
     "icsp_encode_resident", "icsp_sync", "icsp_download", "icsp_device_view", "icsp_download_debug",
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
+    "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
 ]
-KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack"]
+KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode"]
 
 
 class Params(C.Structure):
@@ -72,6 +73,10 @@ def load() -> C.CDLL:
         lib.icsp_pack_bits.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_uint64)]
         lib.icsp_bitstream_assemble.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), vp, C.c_size_t,
                                                 C.POINTER(C.c_size_t)]
+        lib.icsp_parse_header.argtypes = [vp, C.c_size_t, C.POINTER(Params)]
+        lib.icsp_parse_bitstream.argtypes = [vp, C.c_size_t, C.c_int, vp, vp, vp, vp]
+        lib.icsp_upload_syntax.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
+        lib.icsp_decode_resident.argtypes = [vp, C.c_int, C.c_int]
         _lib = lib
     return _lib
 
@@ -112,6 +117,44 @@ def assemble_bitstream(width, height, qp_dc, qp_ac, intra_period, pieces) -> byt
     if rc:
         raise IcspError(lib.icsp_strerror(rc).decode())
     return out[: nbytes.value].tobytes()
+
+
+def parse_header(bs: bytes) -> Params:
+    """readHeader (DEC:14-37).  Needs no GPU."""
+    lib = load()
+    b = np.frombuffer(bs, np.uint8)
+    p = Params()
+    rc = lib.icsp_parse_header(_vp(b), b.size, C.byref(p))
+    if rc:
+        raise IcspError(lib.icsp_strerror(rc).decode())
+    return p
+
+
+def parse_bitstream(bs: bytes, nframes: int):
+    """Host parser, the inverse of write_bitstream (readBlockData, DEC:38-405): (Params, dict of syntax arrays).  Needs no GPU."""
+    lib = load()
+    p = parse_header(bs)
+    b = np.frombuffer(bs, np.uint8)
+    nmb = (p.width // 16) * (p.height // 16)
+    o = dict(levels=np.zeros((nframes, nmb, 6, 64), np.int16), acflag=np.zeros((nframes, nmb, 6), np.uint8),
+             mpm=np.zeros((nframes, nmb, 4), np.uint8), mvd=np.zeros((nframes, nmb, 2), np.int8))
+    rc = lib.icsp_parse_bitstream(_vp(b), b.size, nframes, _vp(o["levels"]), _vp(o["acflag"]), _vp(o["mpm"]), _vp(o["mvd"]))
+    if rc:
+        raise IcspError(lib.icsp_strerror(rc).decode())
+    return p, o
+
+
+def decode_bitstream(bs: bytes, nframes: int, device=0):
+    """.bin image -> decoded frames uint8 [n][W*H*3/2] (what the reference decoder writes to check_test_*_yuv.yuv):
+    host parse, device reconstruction."""
+    p, o = parse_bitstream(bs, nframes)
+    dec = Encoder(p.width, p.height, p.qp_dc, p.qp_ac, p.intra_period, device=device, max_frames=nframes)
+    try:
+        dec.upload_syntax(0, o["levels"], o["mpm"], o["mvd"])
+        dec.decode_resident(0, nframes)
+        return dec.download(0, nframes, what=("recon",))["recon"]
+    finally:
+        dec.close()
 
 
 class Encoder:
@@ -183,6 +226,14 @@ class Encoder:
 
     def keep_coef(self, on=True):
         self._chk(self.lib.icsp_debug_keep_coef(self.ctx, int(on)), "icsp_debug_keep_coef")
+
+    def upload_syntax(self, first, levels, mpm, mvd):
+        lv = np.ascontiguousarray(levels, np.int16); mp = np.ascontiguousarray(mpm, np.uint8); mv = np.ascontiguousarray(mvd, np.int8)
+        self._chk(self.lib.icsp_upload_syntax(self.ctx, first, lv.shape[0], _vp(lv), _vp(mp), _vp(mv)), "icsp_upload_syntax")
+
+    def decode_resident(self, first, n):
+        """Decoder reconstruction (DEC:2083-2272) of the resident syntax of slots [first, first+n) into their recon planes."""
+        self._chk(self.lib.icsp_decode_resident(self.ctx, first, n), "icsp_decode_resident")
 
     def pack_bits(self, first, n, out=None):
         """Device bit packer on the encoded slots [first, first+n): (body bytes as uint8 array, bit count).

@@ -123,6 +123,91 @@ int icsp_bitstream_assemble(const icsp_params_t* p, int npieces, const uint8_t* 
     return ICSP_OK;
 }
 
+// ---- the inverse: readHeader (DEC:14-37) and readBlockData (DEC:38-405) of the reference DECODER
+// (DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp)
+namespace {
+struct BitReader {
+    const uint8_t* p; uint64_t nbits, at; bool over;
+    inline uint32_t bit()                                              // MSB first (DEC:64-70); zeros past the end
+    {
+        if (at >= nbits) { over = true; at++; return 0; }
+        const uint32_t v = (p[at >> 3] >> (7 - (at & 7))) & 1u;
+        at++;
+        return v;
+    }
+    inline uint32_t bits(int n) { uint32_t v = 0; for (int i = 0; i < n; i++) v = (v << 1) | bit(); return v; }
+    // one value of the DC / AC / MV code (DCientropy DEC:407-608, ACientropy DEC:810-1021, MVientropy DEC:2274-2653)
+    inline int value()
+    {
+        uint32_t c = bits(2);
+        if (c == 0) return 0;
+        c = (c << 1) | bit();
+        int e;
+        if (c == 2) e = 0;
+        else if (c < 7) e = (int)c - 2;
+        else { e = 5; while (e < 11 && bit() == 1) e++; if (e == 11) bit(); }
+        const uint32_t s = bit();
+        const int a = (1 << e) + (int)bits(e);
+        return s ? a : -a;
+    }
+    inline void block(int16_t* lv, uint8_t* acflag)
+    {
+        lv[0] = (int16_t)value();
+        const uint32_t ac = bit();
+        *acflag = (uint8_t)ac;
+        if (ac) { at += 63; for (int i = 1; i < 64; i++) lv[i] = 0; }   // DEC:127-132
+        else for (int i = 1; i < 64; i++) lv[i] = (int16_t)value();
+    }
+};
+} // namespace
+
+int icsp_parse_header(const uint8_t* bin, size_t nbytes, icsp_params_t* out)
+{
+    if (!bin || !out) return ICSP_ERR_UNENOUGH_PARAM;
+    if (nbytes < 14 || !(bin[0] == 0 && bin[1] == 73 && bin[2] == 67 && bin[3] == 83 && bin[4] == 80)) return ICSP_ERR_UNCORRECT_PARAM;
+    out->height = bin[5] | (bin[6] << 8); out->width = bin[7] | (bin[8] << 8);
+    out->qp_dc = bin[9]; out->qp_ac = bin[10];
+    out->intra_period = ((bin[12] | (bin[13] << 8)) & 0x1F80) >> 7;      // DEC:29
+    return ICSP_OK;
+}
+
+int icsp_parse_bitstream(const uint8_t* bin, size_t nbytes, int n,
+                         int16_t* levels, uint8_t* acflag, uint8_t* mpm_mode, int8_t* mvd)
+{
+    if (!levels || !acflag || !mpm_mode || !mvd) return ICSP_ERR_UNENOUGH_PARAM;
+    icsp_params_t p;
+    if (int rc = icsp_parse_header(bin, nbytes, &p)) return rc;
+    if (n < 0 || p.width % 16 || p.height % 16 || p.width < 32 || p.height < 16) return ICSP_ERR_UNCORRECT_PARAM;
+    const size_t nmb = (size_t)(p.width / 16) * (p.height / 16);
+    BitReader r{ bin + 14, (uint64_t)(nbytes - 14) * 8, 0, false };
+    for (int f = 0; f < n; f++) {
+        const bool intra = p.intra_period <= 1 || f % p.intra_period == 0;          // DEC.h:293-306
+        for (size_t mb = 0; mb < nmb; mb++) {
+            const size_t o = (size_t)f * nmb + mb;
+            if (intra) {
+                mvd[o * 2] = mvd[o * 2 + 1] = 0;
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t flag = r.bit(), mode = r.bit();
+                    mpm_mode[o * 4 + k] = (uint8_t)(flag | (mode << 1));
+                    r.block(levels + (o * 6 + k) * 64, acflag + o * 6 + k);
+                }
+            } else {
+                r.bit();                                                             // MVmodeflag (DEC:286)
+                mvd[o * 2] = (int8_t)r.value();
+                mvd[o * 2 + 1] = (int8_t)r.value();
+                for (int k = 0; k < 4; k++) { mpm_mode[o * 4 + k] = 0; r.block(levels + (o * 6 + k) * 64, acflag + o * 6 + k); }
+            }
+            r.block(levels + (o * 6 + 4) * 64, acflag + o * 6 + 4);
+            r.block(levels + (o * 6 + 5) * 64, acflag + o * 6 + 5);
+            // Running past the end is an error, except inside the stream's very last macroblock: the reference writes its
+            // final partial byte right-aligned (ENC:4956) and reads it MSB-first (DEC:64-70), so the last few values of
+            // a reference stream can parse as longer codes than were written; the reference reads its zeroed tail there.
+            if ((r.over || r.at > r.nbits) && !(f == n - 1 && mb == nmb - 1)) return ICSP_ERR_RANGE;
+        }
+    }
+    return ICSP_OK;
+}
+
 int icsp_write_bitstream(const icsp_params_t* p, int n, const int16_t* levels, const uint8_t* acflag,
                          const uint8_t* mpm_mode, const int8_t* mvd, uint8_t* out, size_t cap, size_t* out_bytes)
 {

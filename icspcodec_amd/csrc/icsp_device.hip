@@ -212,6 +212,7 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
 
 #include "icsp_blk8.hip.inc"
 #include "icsp_pack.hip.inc"
+#include "icsp_dec.hip.inc"
 
 // ------------------------------------------------------------------------------------------------ host side
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return ICSP_ERR_HIP; } } while (0)
@@ -376,6 +377,57 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     return 0;
 }
 
+template <int NW> void launch_dec_luma(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_dec_intra_luma32<NW>), dim3(G), dim3(NW * 64), 0, st, g, fs, b);
+}
+
+// Decode slots [first, first+n) from the syntax arrays in place (levels, mpm, mvd) into recon.  One launch resolves every
+// frame's serial chains, then the I frames' luma wavefront runs beside their chroma, then one parallel launch per P step.
+int decode_range(icsp_ctx* ctx, int first, int n)
+{
+    const Geo& g = ctx->g;
+    const int L = ctx->p.intra_period > 1 ? ctx->p.intra_period : 1;     // header period 0 or 1: every frame intra (DEC.h:293)
+    if (first % L != 0) return ICSP_ERR_RANGE;
+    if (n == 0) return 0;
+    DevBufs b = ctx->b;
+    b.coef = nullptr;
+    hipStream_t st = ctx->stream, s2 = ctx->stream2;
+    const int G = (n + L - 1) / L;
+    launch_timed(ctx, ICSP_K_DECODE, st, [&] {
+        hipLaunchKernelGGL(k_dec_serial, dim3(n), dim3(256), (size_t)g.nmb * 16, st, g, first, n, L, b);
+    });
+    {
+        FrameSel fs{ first, L, G };
+        hipEventRecord(ctx->ev_fork, st);
+        hipStreamWaitEvent(s2, ctx->ev_fork, 0);
+        launch_timed(ctx, ICSP_K_DECODE, st, [&] {
+            const int need = ctx->intra_waves;
+            const int nw = (G > ctx->n_cu) ? (need < 8 ? need : 8) : need;
+            if (nw <= 2)       launch_dec_luma<2>(g, fs, b, G, st);
+            else if (nw <= 4)  launch_dec_luma<4>(g, fs, b, G, st);
+            else if (nw <= 6)  launch_dec_luma<6>(g, fs, b, G, st);
+            else if (nw <= 8)  launch_dec_luma<8>(g, fs, b, G, st);
+            else if (nw <= 11) launch_dec_luma<11>(g, fs, b, G, st);
+            else               launch_dec_luma<16>(g, fs, b, G, st);
+        });
+        const long long nblk = (long long)G * g.nmb * 2;
+        launch_timed(ctx, ICSP_K_DECODE, s2, [&] { hipLaunchKernelGGL(k_dec_blocks, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s2, g, fs, b, 4, 2, 0); });
+        hipEventRecord(ctx->ev_join, s2);
+        hipStreamWaitEvent(st, ctx->ev_join, 0);
+    }
+    for (int i = 1; i < L; i++) {
+        int Gi = 0;
+        for (int gop = 0; gop < G; gop++) if (gop * L + i < n) Gi++;
+        if (Gi == 0) break;
+        FrameSel fs{ first + i, L, Gi };
+        const long long nblk = (long long)Gi * g.nmb * 6;
+        launch_timed(ctx, ICSP_K_DECODE, st, [&] { hipLaunchKernelGGL(k_dec_blocks, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
     // 32-lane form: two blocks per wave.  `need` waves cover the widest wavefront step in one round.
@@ -416,7 +468,7 @@ const char* icsp_last_error(const icsp_ctx_t* ctx) { return ctx ? ctx->err.c_str
 
 const char* icsp_kernel_name(int k)
 {
-    static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack" };
+    static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode" };
     return (k >= 0 && k < ICSP_K_COUNT) ? names[k] : "?";
 }
 
@@ -462,6 +514,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if ((e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
+    if ((e = hipFuncSetAttribute((const void*)k_dec_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)) != hipSuccess)
+        return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
     for (int k = 1; k < ctx->p_groups; k++) {
         if ((e = hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, prio_hi)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
         if ((e = hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
@@ -559,6 +613,28 @@ int icsp_download(icsp_ctx_t* ctx, int first, int n, int16_t* levels, uint8_t* a
     HIPCHK(hipStreamSynchronize(st));
     if (ctx->profiling) collect_profile(ctx);
     return ICSP_OK;
+}
+
+int icsp_upload_syntax(icsp_ctx_t* ctx, int first, int n, const int16_t* levels, const uint8_t* mpm, const int8_t* mvd)
+{
+    if (!ctx || !levels || !mpm || !mvd) return ICSP_ERR_UNENOUGH_PARAM;
+    if (int rc = check_range(ctx, first, n)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t nmb = ctx->g.nmb, f = first, c = n;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemcpyAsync(ctx->b.levels + f * nmb * 384, levels, c * nmb * 384 * sizeof(int16_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->b.mpm + f * nmb * 4, mpm, c * nmb * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->b.mvd + f * nmb * 2, mvd, c * nmb * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return ICSP_OK;
+}
+
+int icsp_decode_resident(icsp_ctx_t* ctx, int first, int n)
+{
+    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    if (int rc = check_range(ctx, first, n)) return rc;
+    HIPCHK(hipSetDevice(ctx->device));
+    return decode_range(ctx, first, n);
 }
 
 int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap, uint64_t* nbits)

@@ -94,7 +94,7 @@ int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
 
 /* ---- per-kernel timing with HIP events on the launch stream ---------------------------------- */
-enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_CHROMA_DC, ICSP_K_RESIDUAL, ICSP_K_ME, ICSP_K_FRAME_SERIAL, ICSP_K_PACK, ICSP_K_COUNT };
+enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_CHROMA_DC, ICSP_K_RESIDUAL, ICSP_K_ME, ICSP_K_FRAME_SERIAL, ICSP_K_PACK, ICSP_K_DECODE, ICSP_K_COUNT };
 /* on: 0 = off, 1 = time every kernel, otherwise a mask with bit (k+1) set for each kernel k to time (events cost a few
  * microseconds per launch, so the bench times only the dominant kernel inside its timed region). */
 int icsp_profile_enable(icsp_ctx_t* ctx, int on);
@@ -125,6 +125,21 @@ int icsp_pack_bits(icsp_ctx_t* ctx, int first_frame, int n, uint8_t* body, size_
  * identical to icsp_write_bitstream on the same frames.  *out_bytes = 14 + total_bits/8 + 1. */
 int icsp_bitstream_assemble(const icsp_params_t* params, int npieces, const uint8_t* const* pieces,
                             const uint64_t* piece_bits, uint8_t* out, size_t cap, size_t* out_bytes);
+
+/* ---- decoder side: DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp ---- */
+/* Host: readHeader (DEC:14-37).  intra_period is the header field as stored: 1 (or 0) = every frame intra (DEC.h:293). */
+int icsp_parse_header(const uint8_t* bin, size_t nbytes, icsp_params_t* out);
+/* Host: readBlockData (DEC:38-405): the .bin image -> the syntax arrays of frames [0, n) in the layouts above.
+ * ICSP_ERR_RANGE when the stream ends early (the final macroblock may run into the reference's own garbled last byte). */
+int icsp_parse_bitstream(const uint8_t* bin, size_t nbytes, int n,
+                         int16_t* levels, uint8_t* acflag, uint8_t* mpm_mode, int8_t* mvd);
+/* H2D of parsed syntax into slots [first, first+n) of a context created with the stream's parameters. */
+int icsp_upload_syntax(icsp_ctx_t* ctx, int first_frame, int n, const int16_t* levels, const uint8_t* mpm_mode, const int8_t* mvd);
+/* Device: allintraPredictionDecode / intraPredictionDecode / interPredictionDecode (DEC:2083-2272) on resident syntax
+ * (uploaded, or left by icsp_encode_resident): decoded planes into `recon` of slots [first, first+n), first GOP aligned.
+ * Uses the decoder's own cosine table (double literals, DEC.h:19-27), so the output is the reference DECODER's, which
+ * differs from the encoder's reconstruction by a grey level on a few pixels.  Asynchronous; fetch with icsp_download. */
+int icsp_decode_resident(icsp_ctx_t* ctx, int first_frame, int n);
 
 #ifdef __cplusplus
 }
