@@ -167,6 +167,18 @@ def main():
     pack_dt = (time.perf_counter() - t0) / 3
     pack_ms = enc.profile_get()["k_pack"]
     enc.profile(False)
+
+    def decode_fps(e):
+        """f4: decoder reconstruction of the resident syntax (overwrites the recon planes; run after they were used)."""
+        for _ in range(2):
+            e.decode_resident(0, NFRAMES)
+        e.sync()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            e.decode_resident(0, NFRAMES)
+        e.sync()
+        return NFRAMES * 5 / (time.perf_counter() - t0)
+    dec_ai_fps = decode_fps(enc)
     enc.close()
     fps = world * NFRAMES * a.steps / dt
     kern_ms = ms_ai / max(n_ai, 1)
@@ -180,6 +192,7 @@ def main():
     dt2, prof2, _ = timed(enc2, NFRAMES, steps2, min(a.warmup, 2), "k_me")
     recon2 = enc2.download(0, NFRAMES, what=("recon",))["recon"]
     psnr_ip = clipgen.psnr_y(clip2, recon2, W, H)
+    dec_ip_fps = decode_fps(enc2)
     enc2.close()
     fps2 = world * NFRAMES * steps2 / dt2
 
@@ -217,6 +230,8 @@ def main():
                         "pack_and_copy_ms": round(pack_dt * 1e3, 3), "upload_encode_pack_fps": round(NFRAMES / e2e_dt, 1),
                         "note": "5 kernels (count, 2 scans, zero, pack) + D2H of the bits only; pcie_inclusive_fps copies "
                                 "levels/flags/vectors/recon back instead"},
+        "decode": {"all_intra_fps": round(dec_ai_fps, 1), "ippp_fps": round(dec_ip_fps, 1),
+                   "note": "device reconstruction of the resident syntax of the same 300 frames (icsp_decode_resident), this rank"},
         "ippp": {"workload": "stefanlike_cif 300f, --intraPeriod 10, QP=8 (BASELINE configs[2])", "value": round(fps2, 1),
                  "unit": "frames/s", "ms_per_step": round(dt2 / steps2 * 1e3, 4), "psnr_y_db": round(psnr_ip, 4),
                  "read_roofline_frac": round(fps2 / world * read_mean_ip / 1e9 / HBM_PEAK_GBS, 5),

@@ -51,3 +51,36 @@ def test_cli_outputs_equal_reference_files(tmp_path, golden_dir, period, extra):
     binp = tmp_path / f"foremanlike_compCIF_{qp}_{qp}_{period}.bin"
     assert hashlib.sha256(binp.read_bytes()).hexdigest() == ref["bin_sha256"]
     assert hashlib.sha256((tmp_path / "test_yuv.yuv").read_bytes()).hexdigest() == ref["recon_sha256"]
+
+
+DEC = os.path.join(ROOT, "icspcodec_amd", "icsp_dec")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("idx", [0, 1])
+def test_decoder_cli_writes_reference_files(tmp_path, golden_dir, idx):
+    """icsp_enc -> icsp_dec with the reference decoder's command line (decode.cpp:4-27): the decoded file and the PSNR line
+    equal what the reference decoder binary produced for the same stream (tests/golden/decoded.json)."""
+    import re
+    case = json.load(open(os.path.join(golden_dir, "decoded.json")))[idx]
+    name, n, qp, period = case["clip"], case["nframes"], case["qp"], case["intra_period"]
+    clip = clipgen.synth_clip(name, n)
+    fn = clipgen.file_name(name, n)
+    os.makedirs(tmp_path / "output"); os.makedirs(tmp_path / "data")
+    clip.tofile(tmp_path / "data" / fn)
+    r = subprocess.run([ENC, "-i", fn, "-n", str(n), "-q", str(qp), "--intraPeriod", str(period)], cwd=tmp_path / "data",
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout
+    binname = f"{name}_compCIF_{qp}_{qp}_{period}.bin"
+    bs = (tmp_path / "data" / binname).read_bytes()
+    assert hashlib.sha256(bs).hexdigest() == case["bin_sha256"]
+    (tmp_path / "output" / binname).write_bytes(bs)
+    r = subprocess.run([DEC, str(n), binname, str(qp), str(qp), str(period), fn], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 0, r.stdout
+    out = tmp_path / ("check_test_intra_yuv.yuv" if period == 1 else "check_test_inter_yuv.yuv")
+    assert hashlib.sha256(out.read_bytes()).hexdigest() == case["decoded_sha256"]
+    line = (tmp_path / "experimental_Result_Decoding.txt").read_text()
+    m = re.fullmatch(r"decoding time: [0-9.]+\(s\) PSNR: ([0-9.]+) QPDC: (\d+)  QPAC: (\d+) Period: (\d+)\n", line)
+    assert m and abs(float(m.group(1)) - case["psnr"]) < 1.5e-4 and (int(m.group(2)), int(m.group(3)), int(m.group(4))) == (qp, qp, period)
+    r = subprocess.run([DEC, str(n), "nope.bin", "1", "1", "1", fn], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert r.returncode == 255 and r.stdout.startswith(b"fail to load output")
