@@ -150,6 +150,23 @@ def test_hd_1088p_config5_geometry():
     _cmp(got, po.encode_sequence(clip, w, h, 16, 16, 3, nthreads=3), "1088p: ")
 
 
+def test_largest_supported_frame_2048x1088():
+    """Exactly the 8704-macroblock limit of the header: the per-frame kernels stage a whole frame's chain inputs in LDS
+    (k_frame_serial 130 KB, k_dec_serial 139 KB + 16 KB static of the 160 KB).  I + P, encode, device packer, decode."""
+    w, h = 2048, 1088
+    clip = clipgen.synth_clip("mobilelike", 2, width=w, height=h)
+    enc = capi.Encoder(w, h, 16, 16, 2, max_frames=2)
+    got = enc.encode(clip)
+    bs = enc.pack_bitstream(0, 2)
+    enc.decode_resident(0, 2)
+    dec = enc.download(0, 2, what=("recon",))["recon"]
+    enc.close()
+    want = po.encode_sequence(clip, w, h, 16, 16, 2, nthreads=2)
+    _cmp(got, want, "2048x1088: ")
+    assert bs == capi.write_bitstream(w, h, 16, 16, 2, want["levels"], want["acflag"], want["mpm"], want["mvd"])
+    assert np.array_equal(dec, po.decode_sequence(want["levels"], want["mpm"], want["mvd"], w, h, 16, 16, 2))
+
+
 def test_4cif_all_intra_and_size_limit():
     w, h = 704, 576
     clip = clipgen.synth_clip("mobilelike", 2, width=w, height=h)
