@@ -402,7 +402,8 @@ int decode_range(icsp_ctx* ctx, int first, int n)
         hipEventRecord(ctx->ev_fork, st);
         hipStreamWaitEvent(s2, ctx->ev_fork, 0);
         launch_timed(ctx, ICSP_K_DECODE, st, [&] {
-            const int need = ctx->intra_waves;
+            const int diag = g.rows8 < g.cols8 ? g.rows8 : g.cols8;              // widest anti-diagonal, 2 blocks per wave
+            const int need = (diag + 1) / 2;
             const int nw = (G > ctx->n_cu) ? (need < 8 ? need : 8) : need;
             if (nw <= 2)       launch_dec_luma<2>(g, fs, b, G, st);
             else if (nw <= 4)  launch_dec_luma<4>(g, fs, b, G, st);
