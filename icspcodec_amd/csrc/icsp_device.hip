@@ -228,6 +228,10 @@ struct icsp_ctx {
     int device, max_frames, intra_waves, n_cu;
     hipStream_t stream, stream2;      // stream2: I-frame chroma beside the luma wavefront kernel
     hipEvent_t ev_fork, ev_join;
+    // all-intra batches: stream2's chroma work and the luma kernel touch disjoint data, so consecutive encodes need no
+    // cross-stream events at all; the join is deferred until something reads results (s2_dirty), the fork happens only
+    // after other work was queued on `stream` (st_ahead) or when an outside producer uses the stream (always_sync)
+    bool s2_dirty, st_ahead, always_sync;
     int p_groups;                     // GOP groups whose P-step chains run on separate streams
     hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
     hipEvent_t ev_pjoin[kMaxPGroups];
@@ -316,6 +320,14 @@ int intra_waves_needed(const Geo& g)
 
 void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st);
 
+void join_s2(icsp_ctx* ctx)
+{
+    if (!ctx->s2_dirty) return;
+    hipEventRecord(ctx->ev_join, ctx->stream2);
+    hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+    ctx->s2_dirty = false;
+}
+
 int encode_range(icsp_ctx* ctx, int first, int n)
 {
     const Geo& g = ctx->g;
@@ -331,15 +343,20 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     {
         FrameSel fs{ first, L, G };
         hipStream_t s2 = ctx->stream2;
-        hipEventRecord(ctx->ev_fork, st);
-        hipStreamWaitEvent(s2, ctx->ev_fork, 0);
+        const bool lazy = (L == 1) && !ctx->always_sync;
+        if (!lazy || ctx->st_ahead) {
+            hipEventRecord(ctx->ev_fork, st);
+            hipStreamWaitEvent(s2, ctx->ev_fork, 0);
+            ctx->st_ahead = false;
+        }
         launch_timed(ctx, ICSP_K_INTRA_LUMA, st, [&] { launch_intra_luma(ctx, g, fs, b, G, st); });
         const long long nblk = (long long)G * g.nmb * 2;
         launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s2, g, fs, b, 4, 2, 0); });
-        hipEventRecord(ctx->ev_join, s2);
-        hipStreamWaitEvent(st, ctx->ev_join, 0);
+        ctx->s2_dirty = true;
+        if (!lazy) join_s2(ctx);
     }
+    if (L > 1) ctx->st_ahead = true;                   // the P steps below write what the next call's chroma kernels write
     // ---- steps 1..L-1: the i-th P frame of every GOP that has one.  A P step is a chain of dependent kernels of which
     //      k_frame_serial is latency-bound (one workgroup per frame) and leaves most of the chip idle: the GOPs are split
     //      into groups, each running its own chain on its own stream, so one group's serial kernel overlaps the others'
@@ -394,6 +411,8 @@ int decode_range(icsp_ctx* ctx, int first, int n)
     b.coef = nullptr;
     hipStream_t st = ctx->stream, s2 = ctx->stream2;
     const int G = (n + L - 1) / L;
+    join_s2(ctx);
+    ctx->st_ahead = true;
     launch_timed(ctx, ICSP_K_DECODE, st, [&] {
         hipLaunchKernelGGL(k_dec_serial, dim3(n), dim3(256), (size_t)g.nmb * 16, st, g, first, n, L, b);
     });
@@ -502,6 +521,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(&ctx->b, 0, sizeof(ctx->b));
     memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0;
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
+    ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured: 2 groups +7 %, 3 no better, more streams than hardware queues collapse
     if (const char* v = getenv("ICSP_P_GROUPS")) { int k = atoi(v); if (k >= 1 && k <= kMaxPGroups) ctx->p_groups = k; }
@@ -578,6 +598,8 @@ int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
     if (!ctx || !yuv) return ICSP_ERR_UNENOUGH_PARAM;
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
+    join_s2(ctx);                                      // chroma kernels of an earlier encode may still read the frames
+    ctx->st_ahead = true;
     HIPCHK(hipMemcpyAsync(ctx->d_frames + (size_t)first * ctx->g.fsz, yuv, (size_t)n * ctx->g.fsz, hipMemcpyHostToDevice, ctx->stream));
     return ICSP_OK;
 }
@@ -594,6 +616,7 @@ int icsp_sync(icsp_ctx_t* ctx)
 {
     if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
     HIPCHK(hipSetDevice(ctx->device));
+    join_s2(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (ctx->profiling) collect_profile(ctx);
     return ICSP_OK;
@@ -606,6 +629,7 @@ int icsp_download(icsp_ctx_t* ctx, int first, int n, int16_t* levels, uint8_t* a
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nmb = ctx->g.nmb, f = first, c = n;
     hipStream_t st = ctx->stream;
+    join_s2(ctx);
     if (levels) HIPCHK(hipMemcpyAsync(levels, ctx->b.levels + f * nmb * 384, c * nmb * 384 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     if (acflag) HIPCHK(hipMemcpyAsync(acflag, ctx->b.acflag + f * nmb * 6, c * nmb * 6, hipMemcpyDeviceToHost, st));
     if (mpm) HIPCHK(hipMemcpyAsync(mpm, ctx->b.mpm + f * nmb * 4, c * nmb * 4, hipMemcpyDeviceToHost, st));
@@ -623,6 +647,8 @@ int icsp_upload_syntax(icsp_ctx_t* ctx, int first, int n, const int16_t* levels,
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nmb = ctx->g.nmb, f = first, c = n;
     hipStream_t st = ctx->stream;
+    join_s2(ctx);
+    ctx->st_ahead = true;
     HIPCHK(hipMemcpyAsync(ctx->b.levels + f * nmb * 384, levels, c * nmb * 384 * sizeof(int16_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->b.mpm + f * nmb * 4, mpm, c * nmb * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->b.mvd + f * nmb * 2, mvd, c * nmb * 2, hipMemcpyHostToDevice, st));
@@ -647,6 +673,7 @@ int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap,
     *nbits = 0;
     if (n == 0) return ICSP_OK;
     HIPCHK(hipSetDevice(ctx->device));
+    join_s2(ctx);
     const Geo& g = ctx->g;
     const long long cap_grps = ((long long)ctx->max_frames * g.nmb * 6 + kGrpUnits - 1) / kGrpUnits;
     if (!ctx->pk.out) {
@@ -703,6 +730,8 @@ int icsp_device_view(icsp_ctx_t* ctx, icsp_device_view_t* v)
     v->frames = ctx->d_frames; v->levels = ctx->b.levels; v->acflag = ctx->b.acflag; v->mpm_mode = ctx->b.mpm;
     v->mvd = ctx->b.mvd; v->recon = ctx->b.recon; v->stream = (void*)ctx->stream;
     v->max_frames = ctx->max_frames; v->n_mb = ctx->g.nmb;
+    join_s2(ctx);
+    ctx->always_sync = true;           // an outside producer/consumer now shares `stream`: order stream2 against it every time
     return ICSP_OK;
 }
 
@@ -712,6 +741,7 @@ int icsp_download_debug(icsp_ctx_t* ctx, int first, int n, int8_t* mv, uint8_t* 
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nmb = ctx->g.nmb, f = first, c = n;
+    join_s2(ctx);
     if (mv) HIPCHK(hipMemcpyAsync(mv, ctx->b.mv + f * nmb * 2, c * nmb * 2, hipMemcpyDeviceToHost, ctx->stream));
     if (imode) HIPCHK(hipMemcpyAsync(imode, ctx->b.imode + f * nmb * 4, c * nmb * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -737,6 +767,7 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first, int n, double* coef)
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t per = (size_t)ctx->g.nmb * 384;
+    join_s2(ctx);
     HIPCHK(hipMemcpyAsync(coef, ctx->b.coef + (size_t)first * per, (size_t)n * per * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ICSP_OK;
