@@ -5,13 +5,14 @@
 #include <cstdlib>
 int main()
 {
-    const int nframes = 300;
-    icsp_params_t p{352, 288, 8, 8, 10};
+    const int nframes = (getenv("DIAG_HD") ? 8 : 300);
+    const int W = getenv("DIAG_HD") ? 1920 : 352, H = getenv("DIAG_HD") ? 1088 : 288;
+    icsp_params_t p{W, H, 8, 8, getenv("DIAG_HD") ? 4 : 10};
     icsp_ctx_t* ctx = nullptr;
     if (int rc = icsp_create(&ctx, &p, 0, nframes)) { printf("create: %s\n", icsp_strerror(rc)); return 1; }
-    std::vector<uint8_t> clip((size_t)nframes * 152064);
+    std::vector<uint8_t> clip((size_t)nframes * W * H * 3 / 2);
     unsigned x = 12345;
-    for (size_t i = 0; i < clip.size(); i++) { x = x * 1664525u + 1013904223u; clip[i] = (uint8_t)(100 + ((i / 352) % 64) + ((x >> 24) % 9)); }
+    for (size_t i = 0; i < clip.size(); i++) { x = x * 1664525u + 1013904223u; clip[i] = (uint8_t)(100 + ((i / W) % 64) + ((x >> 24) % 9)); }
     icsp_upload(ctx, clip.data(), 0, nframes);
     for (int rep = 0; rep < 5; rep++) { icsp_encode_resident(ctx, 0, nframes); icsp_sync(ctx); }
     unsigned long long d[16];
