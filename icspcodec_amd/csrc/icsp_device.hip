@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_rec[2][512];
+    __shared__ int16_t s_dummy;
     const int slot = fs.first + blockIdx.x * fs.stride;
     const int pl = blockIdx.y;                                 // 0 = Cb, 1 = Cr
     const int cols = g.sw, rows = g.sh, nblk = g.nmb;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
         const int l = threadIdx.x;
         const int q = g.qdc;
         const uint32_t mg = g.mdc;
-        if (rows <= 64) dc_chain_rows64<false>(s_sp, cols, rows, q, mg, l);
+        if (rows <= 64) dc_chain_rows64<false>(s_sp, &s_dummy, cols, rows, q, mg, l);
         else {
             const int nsteps = cols + 2 * (rows - 1);
             for (int t = 0; t < nsteps; t++) {
