@@ -499,7 +499,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     *out = nullptr;
     if (p->width % 16 || p->height % 16 || p->width < 32 || p->width > 4096 || p->height < 16 || p->height > 2304 ||
         (p->width / 16) * (p->height / 16) > 8704 ||      /* k_frame_serial keeps 15 bytes of LDS per macroblock */
-        p->qp_dc <= 0 || p->qp_ac <= 0 || p->intra_period < 0 || max_frames <= 0)
+        p->qp_dc <= 0 || p->qp_ac <= 0 || p->qp_dc > 255 || p->qp_ac > 255 ||      /* one header byte each (ENC.h:207-208) */
+        p->intra_period < 0 || max_frames <= 0)
         return ICSP_ERR_UNCORRECT_PARAM;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ICSP_ERR_NO_DEVICE;
