@@ -89,7 +89,7 @@ __device__ unsigned long long g_diag[16];
 struct Geo {
     int W, H, sw, sh, nmb, cols8, rows8, cw, ch;
     int qdc, qac;
-    uint32_t mdc, mac;                // ceil(2^32/q): |t|/q == umulhi(|t|, m) for |t| < 2^16, q > 1
+    uint32_t mdc, mac;                // floor(2^32/q) + 1: |t|/q == umulhi(|t|, m) for |t| < 2^16, q > 1
     long long fsz;                    // bytes per frame = W*H*3/2
 };
 struct FrameSel { int first, stride, count; };     // item i -> frame slot first + i*stride
@@ -514,8 +514,10 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     g.W = p->width; g.H = p->height; g.sw = g.W / 16; g.sh = g.H / 16; g.nmb = g.sw * g.sh;
     g.cols8 = 2 * g.sw; g.rows8 = 2 * g.sh; g.cw = g.W / 2; g.ch = g.H / 2;
     g.qdc = p->qp_dc; g.qac = p->qp_ac;
-    g.mdc = (uint32_t)((0x100000000ull + g.qdc - 1) / (unsigned)g.qdc);     // unused when q == 1 (would not fit 32 bits)
-    g.mac = (uint32_t)((0x100000000ull + g.qac - 1) / (unsigned)g.qac);
+    // magic = floor(2^32/q) + 1 (== ceil(2^32/q) unless q is a power of two): |t|/q == umulhi(|t|, magic) for |t| < 2^16, and
+    // strictly above 2^32/q, which the signed form in the DC chains needs (a negative multiple of q must not divide exactly)
+    g.mdc = (uint32_t)(0x100000000ull / (unsigned)g.qdc + 1);               // unused when q == 1 (would not fit 32 bits)
+    g.mac = (uint32_t)(0x100000000ull / (unsigned)g.qac + 1);
     g.fsz = (long long)g.W * g.H * 3 / 2;
     ctx->intra_waves = intra_waves_needed(g);
     ctx->n_cu = 256;
