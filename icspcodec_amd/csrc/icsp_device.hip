@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
     extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];
     __shared__ int s_rec[2][512];
     __shared__ int16_t s_dummy;
+    __shared__ int s_dummy32;
     const int slot = fs.first + blockIdx.x * fs.stride;
     const int pl = blockIdx.y;                                 // 0 = Cb, 1 = Cr
     const int cols = g.sw, rows = g.sh, nblk = g.nmb;
@@ -184,28 +185,7 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
         const int q = g.qdc;
         const uint32_t mg = g.mdc;
         if (rows <= 64) dc_chain_rows64<false>(s_sp, &s_dummy, cols, rows, q, mg, l);
-        else {
-            const int nsteps = cols + 2 * (rows - 1);
-            for (int t = 0; t < nsteps; t++) {
-                int r_lo = t - (cols - 1); r_lo = (r_lo <= 0) ? 0 : (r_lo + 1) >> 1;
-                const int r_hi = min(rows - 1, t >> 1);
-                for (int r = r_lo + l; r <= r_hi; r += 64) {
-                    const int c = t - 2 * r;
-                    const int cl = max(c - 1, 0), cr = min(c + 1, cols - 1), ru = (r + 1) & 1, rc = r & 1;
-                    const int L = s_rec[rc][cl], U = s_rec[ru][c], UL = s_rec[ru][cl], UR = s_rec[ru][cr];
-                    const int med = med3i(L, U, (c == cols - 1) ? UL : UR);
-                    const int p = (r == 0 && c == 0) ? 1024 : (r == 0) ? L : (c == 0) ? U : med;
-                    const double S = (double)s_sp[r * cols + c];
-                    const double dc = ((S * kIrt2) * kIrt2) * (1. / 4.) - p;
-                    const int t0 = (int)floor(dc + 0.5);
-                    const uint32_t a = (uint32_t)abs(t0);
-                    const int lv = (int)((q == 1) ? a : __umulhi(a, mg));
-                    s_rec[rc][c] = ((t0 < 0) ? -lv : lv) * q + p;
-                    s_sp[r * cols + c] = (int16_t)p;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
+        else            dc_chain_banded<false>(s_sp, &s_dummy, &s_dummy32, &s_rec[0][0], cols, rows, q, mg, l);
     }
     __syncthreads();
     for (int n = threadIdx.x; n < nblk; n += 256) b.dcpred[(fb + n) * 6 + 4 + pl] = s_sp[n];
@@ -384,7 +364,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
                 hipLaunchKernelGGL((k_me<false, 4>), dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, sk, g, fs, b);
                 hipLaunchKernelGGL((k_me<true, 16>), dim3((unsigned)((nmbs + 15) / 16)), dim3(1024), 0, sk, g, fs, b);
             });
-            launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] { hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(256), ((size_t)g.nmb * 15 + 15) & ~(size_t)15, sk, g, fs, b); });
+            launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] { hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), ((size_t)g.nmb * 15 + 15) & ~(size_t)15, sk, g, fs, b); });
             launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, sk, g, fs, b, 0, 6, 1); });
         }
         if (!any) break;
