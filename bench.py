@@ -9,7 +9,8 @@ checkout).  Inputs are uploaded to HBM before the timed region.  With N GPUs eve
 shard (closed GOPs / independent frames shard with no collective: weak scaling); value = frames of all ranks / max
 rank time.  Rank 0 prints ONE JSON line.  Secondary figures in the same line: the IPPP workload (configs[2]:
 `stefanlike` 300 f, --intraPeriod 10, QP 8), reconstructed PSNR, the per-kernel HIP-event timing and roofline of the
-dominant kernel, and the CPU baseline (the reference's own --EnMultiThread path, timed on this box's host cores).
+dominant kernel, the CPU baseline (the reference's own --EnMultiThread path, timed on this box's host cores), the device
+bit packer (`device_pack`) and the device decoder (`decode`).
 """
 from __future__ import annotations
 

@@ -16,6 +16,9 @@
 // Mapping (icsp_blk8.hip.inc): 8 lanes per 8x8 block for the throughput kernels (a lane owns one row or column, 8 blocks
 // per wave), 32 lanes per block for the latency-bound intra kernel; the two 1-D passes of each transform exchange data
 // through a 528-byte LDS tile per block.
+// Pieces: icsp_me.hip.inc (motion search, per-frame serial kernel with the DC-DPCM chains), icsp_blk8.hip.inc (transform
+// chain, k_residual8, k_intra_luma32), icsp_pack.hip.inc (bit packer), icsp_dec.hip.inc (decoder, §8 f4);
+// the host half of the ABI (bit writer / assembler / parser) is icsp_bitstream.cpp.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -46,7 +46,7 @@ typedef enum {
 
 typedef struct {
     int width, height;   /* luma size, multiples of 16 (the reference hard-codes 352x288, encoder_main.cpp:20) */
-    int qp_dc, qp_ac;    /* quantiser steps, > 0 (README: 1, 8 or 16) */
+    int qp_dc, qp_ac;    /* quantiser steps, 1..255: one header byte each (README: 1, 8 or 16) */
     int intra_period;    /* 0 = every frame is an I frame (ALL_INTRA, ICSP_Codec_Encoder.h:18); k>0: frame n is I iff n%k==0 */
 } icsp_params_t;
 
