@@ -102,6 +102,7 @@ struct DevBufs {
     int8_t* mv; uint8_t* imode;       // debug taps / inter-kernel data
     uint32_t* me_ent;                 // [slot][nmb][4] packed (mvx, mvy, next state)
     int* me_flag;                     // [slot] set by k_me<false> when a macroblock of the frame broke out of its walk early
+    int* me_done;                     // [slot] k_serial_fused: macroblocks of the frame whose four-state search is published
     int16_t* me_sums;                 // [slot][nmb][4][6] residual block sums of a P-frame MB for each search state
     int16_t* dcpred;                  // [slot][nmb][6] DC predictors
     double* coef;                     // optional [slot][nmb][6][64]
@@ -216,6 +217,7 @@ struct icsp_ctx {
     // cross-stream events at all; the join is deferred until something reads results (s2_dirty), the fork happens only
     // after other work was queued on `stream` (st_ahead) or when an outside producer uses the stream (always_sync)
     bool s2_dirty, st_ahead, always_sync;
+    bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
     int p_groups;                     // GOP groups whose P-step chains run on separate streams
     hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
     hipEvent_t ev_pjoin[kMaxPGroups];
@@ -363,11 +365,18 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             hipStream_t sk = k == 0 ? st : ctx->pstream[k];
             FrameSel fs{ first + g0 * L + i, L, Gi };
             const long long nmbs = (long long)Gi * g.nmb, nblk = nmbs * 6;
+            const size_t serial_lds = ((size_t)g.nmb * 15 + 15) & ~(size_t)15;
+            // small frames, not too many of them: the four-state search rides in the serial kernel's launch (one kernel
+            // boundary less per step); else two launches, the serial one with 1024 threads for its staging loops
+            const bool fused = g.nmb < 2048 && Gi <= 1024 && !ctx->no_fuse;
             launch_timed(ctx, ICSP_K_ME, sk, [&] {
                 hipLaunchKernelGGL((k_me<false, 4>), dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, sk, g, fs, b);
-                hipLaunchKernelGGL((k_me<true, 16>), dim3((unsigned)((nmbs + 15) / 16)), dim3(1024), 0, sk, g, fs, b);
+                if (!fused) hipLaunchKernelGGL((k_me<true, 16>), dim3((unsigned)((nmbs + 15) / 16)), dim3(1024), 0, sk, g, fs, b);
             });
-            launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] { hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), ((size_t)g.nmb * 15 + 15) & ~(size_t)15, sk, g, fs, b); });
+            launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
+                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3((unsigned)(Gi + (nmbs + 3) / 4)), dim3(256), serial_lds, sk, g, fs, b, Gi);
+                else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
+            });
             launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, sk, g, fs, b, 0, 6, 1); });
         }
         if (!any) break;
@@ -509,6 +518,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0;
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
+    ctx->no_fuse = getenv("ICSP_NO_FUSE") != nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured: 2 groups +7 %, 3 no better, more streams than hardware queues collapse
     if (const char* v = getenv("ICSP_P_GROUPS")) { int k = atoi(v); if (k >= 1 && k <= kMaxPGroups) ctx->p_groups = k; }
@@ -545,6 +555,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ALLOC(ctx->b.me_sums, nf * nmb * 24 * sizeof(int16_t));
     ALLOC(ctx->b.me_flag, nf * sizeof(int));
     hipMemsetAsync(ctx->b.me_flag, 0, nf * sizeof(int), ctx->stream);
+    ALLOC(ctx->b.me_done, nf * sizeof(int));
+    hipMemsetAsync(ctx->b.me_done, 0, nf * sizeof(int), ctx->stream);
     ALLOC(ctx->b.dcpred, nf * nmb * 6 * sizeof(int16_t));
 #undef ALLOC
     hipMemsetAsync(ctx->b.mpm, 0, nf * nmb * 4, ctx->stream);
@@ -568,7 +580,7 @@ int icsp_destroy(icsp_ctx_t* ctx)
     for (auto& e : ctx->ev_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     for (auto& e : ctx->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
     hipFree(ctx->d_frames); hipFree(ctx->b.recon); hipFree(ctx->b.levels); hipFree(ctx->b.acflag); hipFree(ctx->b.mpm);
-    hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.me_sums); hipFree(ctx->b.me_flag);
+    hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.me_sums); hipFree(ctx->b.me_flag); hipFree(ctx->b.me_done);
     hipFree(ctx->b.dcpred); hipFree(ctx->b.coef);
     hipFree(ctx->pk.grp_bits); hipFree(ctx->pk.grp_off); hipFree(ctx->pk.chunk_bits); hipFree(ctx->pk.chunk_base); hipFree(ctx->pk.out);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);

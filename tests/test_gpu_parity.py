@@ -30,6 +30,7 @@ def _cmp(got, want, ctx=""):
     ("foremanlike", 2, 16, 0), ("foremanlike", 3, 8, 0), ("mobilelike", 2, 1, 0),
     ("stefanlike", 3, 8, 3), ("foremanlike", 6, 16, 3), ("footballlike", 4, 16, 4),
     ("staticlike", 4, 1, 4), ("akiyolike", 5, 16, 5), ("tablelike", 7, 8, 3),
+    ("staticlike", 36, 16, 6),          # six GOPs whose every P frame has early breaks: the fused kernel's waiting path
 ])
 def test_sequence_matches_oracle(name, n, q, period):
     clip = clipgen.synth_clip(name, n)

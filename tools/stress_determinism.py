@@ -30,7 +30,8 @@ def run(name, n, q, period, reps, w=352, h=288):
 ok = True
 ok &= run("foremanlike", 300, 16, 0, 25)
 ok &= run("stefanlike", 300, 8, 10, 25)
-ok &= run("staticlike", 60, 1, 6, 15)
+ok &= run("staticlike", 300, 1, 6, 40)      # every frame flagged: the fused kernel's cross-workgroup wait on every P step
+ok &= run("staticlike", 60, 16, 3, 40)
 ok &= run("mobilelike", 64, 16, 4, 10, 704, 576)
 ok &= run("tablelike", 6, 16, 3, 5, 1920, 1088)
 sys.exit(0 if ok else 1)
