@@ -13,7 +13,7 @@ P, NMB = 352 * 288, 396
 
 def short(n):
     for k in ("k_dec_intra_luma32", "k_dec_serial", "k_dec_blocks", "k_intra_luma32", "k_chroma_dc", "k_residual8", "k_me<false",
-              "k_me<true", "k_frame_serial", "k_bits_count", "k_bits_scan", "k_chunk_base", "k_pack_zero", "k_pack"):
+              "k_me<true", "k_serial_fused", "k_frame_serial", "k_bits_count", "k_bits_scan", "k_chunk_base", "k_pack_zero", "k_pack"):
         if k in n:
             return k.replace("<", "_").rstrip("_")
     return n.split("(")[0][-40:]
