@@ -155,6 +155,18 @@ __device__ __forceinline__ int pad_fetch(const uint8_t* plane, int w, int h, int
     return zero ? 0 : v;
 }
 
+// Four consecutive pixels of the padded picture starting at padded column px0 (a multiple of 4; pad and w are too), as one
+// dword: inside the plane it is the plane's dword; in a side pad it is the row's first / last pixel replicated.
+__device__ __forceinline__ uint32_t pad_fetch_dw(const uint8_t* plane, int w, int h, int pad, int py, int px0)
+{
+    const int fy = min(max(py - pad, 0), h - 1), fx = px0 - pad;
+    const uint32_t dw = *(const uint32_t*)(plane + fy * w + min(max(fx, 0), w - 4));
+    uint32_t v = fx < 0 ? (dw & 0xffu) * 0x01010101u : (fx >= w ? (dw >> 24) * 0x01010101u : dw);
+    if (px0 + 3 == w + 2 * pad - 1) v &= 0x00ffffffu;           // the never-written last padded column (ENC:2239-2268)
+    if (py == h + 2 * pad - 1) v = 0;                           // and row
+    return v;
+}
+
 #include "icsp_me.hip.inc"
 
 // ------------------------------------------------------------------------------------------------ I-frame chroma DC chain
