@@ -151,6 +151,23 @@ def test_hd_1088p_config5_geometry():
     _cmp(got, po.encode_sequence(clip, w, h, 16, 16, 3, nthreads=3), "1088p: ")
 
 
+def test_many_small_gops_takes_the_two_launch_path():
+    """More than 1024 GOPs in one call: the per-step launch falls back from k_serial_fused to k_me<true> + k_frame_serial
+    (its serial workgroups must never be able to fill the device while they wait).  Tiny frames, 2200 of them, GOPs of 2;
+    a repeated frame inside some GOPs raises the early-break flags."""
+    w, h, n = 64, 48, 2200
+    base = clipgen.synth_clip("stefanlike", 40, width=w, height=h)
+    clip = np.concatenate([base] * (n // 40))
+    clip[1::8] = clip[0::8]                          # every fourth GOP: P frame identical to its I frame
+    enc = capi.Encoder(w, h, 16, 16, 2, max_frames=n)
+    got = enc.encode(clip)
+    bs = enc.pack_bitstream(0, n)
+    enc.close()
+    want = po.encode_sequence(clip, w, h, 16, 16, 2, nthreads=8)
+    _cmp(got, want, "2200 x 64x48: ")
+    assert bs == capi.write_bitstream(w, h, 16, 16, 2, want["levels"], want["acflag"], want["mpm"], want["mvd"])
+
+
 def test_largest_supported_frame_2048x1088():
     """Exactly the 8704-macroblock limit of the header: the per-frame kernels stage a whole frame's chain inputs in LDS
     (k_frame_serial 130 KB, k_dec_serial 139 KB + 16 KB static of the 160 KB).  I + P, encode, device packer, decode."""
