@@ -32,6 +32,8 @@ P = W * H
 NMB = (W // 16) * (H // 16)
 NFRAMES = 300
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+SETTLE_PASSES = 100            # untimed passes (about 40 ms) before the W warmup steps of every timed leg: the GPU clock ramps
+                               # up over the first tens of milliseconds of load, which would make the figure depend on W and K
 
 # Algorithmic HBM bytes per CIF frame: every input/reference/output byte crosses once.
 #   whole I frame: read 1.5P, write recon 1.5P + levels 3P (int16) + side info 10 B/MB (acflag 6, mpm 4)
@@ -119,6 +121,9 @@ def main():
     def timed(enc, n, steps, warmup, dominant):
         """K timed steps (HIP events only around the dominant kernel, none if it is None), then three untimed passes with
         events on every kernel."""
+        for _ in range(SETTLE_PASSES):              # fixed settle (clock ramp, instruction and TLB warm-up): independent of W
+            enc.encode_resident(0, n)
+        enc.sync()
         for _ in range(warmup):
             enc.encode_resident(0, n)
         enc.sync()

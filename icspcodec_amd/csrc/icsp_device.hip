@@ -270,9 +270,12 @@ void build_me_tables(MeTables& t)
     t.n_union = n;
 }
 
+int collect_profile(icsp_ctx* ctx);
+
 template <typename F> int launch_timed(icsp_ctx* ctx, int kernel, hipStream_t st, F&& f)
 {
     if (!ctx->profiling || !((ctx->prof_mask >> kernel) & 1u)) { f(); return 0; }
+    if (ctx->ev_pool.empty() && ctx->ev_pending.size() >= 8192) collect_profile(ctx);     // keeps the list bounded (this one blocks)
     EvPair e;
     if (!ctx->ev_pool.empty()) { e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
     else { if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return ICSP_ERR_HIP; }
@@ -629,7 +632,8 @@ int icsp_sync(icsp_ctx_t* ctx)
     HIPCHK(hipSetDevice(ctx->device));
     join_s2(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (ctx->profiling) collect_profile(ctx);
+    // event pairs are read out in icsp_profile_get / icsp_profile_reset, not here: a caller timing "launch ... icsp_sync"
+    // must not pay for the bookkeeping of the profiler
     return ICSP_OK;
 }
 
@@ -789,6 +793,17 @@ int icsp_profile_enable(icsp_ctx_t* ctx, int on)
     if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
     ctx->profiling = on != 0;
     ctx->prof_mask = (on == 1) ? 0xffffffffu : ((unsigned)on >> 1);     // 1 = every kernel; otherwise bit (k+1) selects kernel k
+    if (on) {
+        // events are created here, not at the first timed launch: hipEventCreate inside a measured region would be billed to it
+        HIPCHK(hipSetDevice(ctx->device));
+        while (ctx->ev_pool.size() + ctx->ev_pending.size() < 256) {
+            EvPair e;
+            if (hipEventCreate(&e.a) != hipSuccess) break;
+            if (hipEventCreate(&e.b) != hipSuccess) { hipEventDestroy(e.a); break; }
+            e.kernel = 0;
+            ctx->ev_pool.push_back(e);
+        }
+    }
     return ICSP_OK;
 }
 
