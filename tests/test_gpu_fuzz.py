@@ -1,6 +1,8 @@
 """Seeded fuzz: random geometries, quantisers, GOP lengths and pixel statistics (flat, extremes, noise, gradients, exact
 repeats that trigger the search's early break) — every output of the HIP path against the oracle, the device bit packer
 against the host writer, the device decoder against the decoder oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -35,7 +37,7 @@ def _content(rng, kind, n, w, h):
     return np.stack(frames)
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("ICSP_FUZZ_SEEDS", "96"))))     # 1500 seeds were run once per round
 def test_fuzz_case(seed):
     rng = np.random.default_rng(1000 + seed)
     w = 16 * int(rng.integers(2, 11)); h = 16 * int(rng.integers(1, 7))
