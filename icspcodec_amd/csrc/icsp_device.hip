@@ -71,6 +71,7 @@ struct MeTables {
     int     n_union;
 };
 __constant__ MeTables c_me;
+__device__ unsigned g_spin_timeouts;   // bounded waits that ran out (k_serial_fused); never expected, exposed for the tests
 
 #ifdef ICSP_DIAG
 // Diagnostic build only (tools/diag_intra.hip): per-phase shader-cycle shares of one wave, never in the product build.
@@ -785,6 +786,16 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first, int n, double* coef)
     join_s2(ctx);
     HIPCHK(hipMemcpyAsync(coef, ctx->b.coef + (size_t)first * per, (size_t)n * per * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ICSP_OK;
+}
+
+int icsp_debug_spin_timeouts(icsp_ctx_t* ctx, unsigned* count)
+{
+    if (!ctx || !count) return ICSP_ERR_UNENOUGH_PARAM;
+    HIPCHK(hipSetDevice(ctx->device));
+    join_s2(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_spin_timeouts), sizeof(unsigned)));
     return ICSP_OK;
 }
 

@@ -91,6 +91,9 @@ int icsp_download_debug(icsp_ctx_t* ctx, int first_frame, int n, int8_t* mv, uin
 /* When enabled (before encoding), forward-DCT coefficients before DC prediction/quantisation are kept:
  * double[n][nMB][6][64], row-major [v][u] (DCT_block output, ENC:2685-2749).  Costs 8x the level store. */
 int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
+/* Number of bounded device-side waits that expired since the library was loaded (a flagged frame's serial workgroup waits
+ * for that frame's four-state search inside one launch).  Always 0 unless something is broken; syncs the context. */
+int icsp_debug_spin_timeouts(icsp_ctx_t* ctx, unsigned* count);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
 
 /* ---- per-kernel timing with HIP events on the launch stream ---------------------------------- */

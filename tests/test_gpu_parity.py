@@ -36,6 +36,7 @@ def test_sequence_matches_oracle(name, n, q, period):
     clip = clipgen.synth_clip(name, n)
     enc = capi.Encoder(W, H, q, q, period, max_frames=n)
     got = enc.encode(clip)
+    assert enc.spin_timeouts() == 0              # the fused launch's bounded wait never runs out
     enc.close()
     want = po.encode_sequence(clip, W, H, q, q, period)
     _cmp(got, want, f"{name} n={n} q={q} p={period}: ")

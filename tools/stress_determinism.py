@@ -23,7 +23,10 @@ def run(name, n, q, period, reps, w=352, h=288):
         elif hsh != ref:
             print(f"MISMATCH {name} n={n} q={q} p={period} rep={r}")
             return False
+    to = enc.spin_timeouts()
     enc.close()
+    if to:
+        print(f"SPIN TIMEOUTS {to}"); return False
     print(f"ok {name} {w}x{h} n={n} q={q} p={period} x{reps}: {ref[:16]}")
     return True
 
