@@ -133,3 +133,33 @@ def test_assemble_pieces_equals_one_pass_writer():
     assert sum(nb for _, nb in pieces) // 8 + 1 + 14 == len(whole)
     assert capi.assemble_bitstream(W, H, q, q, period, pieces) == whole
     assert capi.assemble_bitstream(W, H, q, q, period, []) == whole[:14] + b"\x00"
+
+
+def test_assemble_random_splits_and_parser_on_garbage():
+    """Bit-wise concatenation at arbitrary bit boundaries; the parser returns a status on garbage instead of crashing."""
+    rng = np.random.default_rng(7)
+    W, H, q, period, n = 64, 48, 8, 3, 6
+    clip = clipgen.synth_clip("tablelike", n, width=W, height=H)
+    o = po.encode_sequence(clip, W, H, q, q, period)
+    whole = capi.write_bitstream(W, H, q, q, period, o["levels"], o["acflag"], o["mpm"], o["mvd"])
+    nb = body_bits(o["levels"], o["acflag"], o["mvd"], period)
+    body = bytearray(whole[14:])
+    if nb % 8:
+        body[-1] = (body[-1] << (8 - nb % 8)) & 0xff
+    bits = np.unpackbits(np.frombuffer(bytes(body), np.uint8))[:nb]
+    for _ in range(20):
+        cuts = sorted(set([0, nb] + list(rng.integers(0, nb, size=int(rng.integers(0, 6))))))
+        pieces = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            seg = bits[a:b]
+            pieces.append((np.packbits(seg).tobytes(), len(seg)))          # zero-padded, MSB first
+        assert capi.assemble_bitstream(W, H, q, q, period, pieces) == whole
+    # garbage after a valid header: ICSP_OK or ICSP_ERR_RANGE, never a crash; a bad header is rejected
+    for _ in range(30):
+        junk = whole[:14] + rng.integers(0, 256, size=int(rng.integers(0, 4000)), dtype=np.uint8).tobytes()
+        try:
+            capi.parse_bitstream(junk, n)
+        except capi.IcspError:
+            pass
+    with pytest.raises(capi.IcspError):
+        capi.parse_bitstream(b"\x00ICS", 1)
