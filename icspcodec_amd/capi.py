@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(HERE, "libicsp_hip.so")
 
 # every symbol include/icsp_hip.h declares
 SYMBOLS = [
-    "icsp_create", "icsp_destroy", "icsp_strerror", "icsp_last_error", "icsp_encode_gop", "icsp_upload",
+    "icsp_create", "icsp_destroy", "icsp_strerror", "icsp_device_count", "icsp_last_error", "icsp_encode_gop", "icsp_upload",
     "icsp_encode_resident", "icsp_sync", "icsp_download", "icsp_device_view", "icsp_download_debug",
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_debug_spin_timeouts", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",

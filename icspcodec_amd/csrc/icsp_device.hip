@@ -495,6 +495,12 @@ const char* icsp_strerror(int s)
 
 const char* icsp_last_error(const icsp_ctx_t* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
+int icsp_device_count(void)
+{
+    int n = 0;
+    return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? n : 0;
+}
+
 const char* icsp_kernel_name(int k)
 {
     static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode" };

@@ -134,14 +134,14 @@ int main(int argc, char* argv[])
     const int L = opt.intra_period > 0 ? opt.intra_period : 1;
     const int ngop = (n + L - 1) / L;
     if (ngpu > ngop) ngpu = ngop;
-    // test hook: ICSP_ENC_SAME_DEVICE=1 runs every shard on device 0, so the multi-shard path (one context and one bit-string
-    // piece per shard, concatenated on the host) can be exercised on a one-GPU box; never set in production
-    const bool same_device = getenv("ICSP_ENC_SAME_DEVICE") != nullptr;
+    // --EnMultiThread N / --gpus N ask for N shards; with fewer devices than that, shards share devices round-robin (each
+    // shard is its own context and host thread), so the reference's thread option still works on a one-GPU box
+    const int ndev = icsp_device_count() > 0 ? icsp_device_count() : 1;
     std::vector<Shard> shards(ngpu);
     int g0 = 0;
     for (int d = 0; d < ngpu; d++) {
         int gcount = ngop / ngpu + (d < ngop % ngpu ? 1 : 0);
-        shards[d].device = same_device ? 0 : d; shards[d].first = g0 * L;
+        shards[d].device = d % ndev; shards[d].first = g0 * L;
         shards[d].count = std::min(n, (g0 + gcount) * L) - g0 * L;
         shards[d].rc = 0; shards[d].bits = 0;
         g0 += gcount;

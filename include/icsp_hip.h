@@ -57,6 +57,7 @@ typedef struct icsp_ctx icsp_ctx_t; /* opaque: device buffers, stream and scratc
 int icsp_create(icsp_ctx_t** out, const icsp_params_t* params, int device_id, int max_frames);
 int icsp_destroy(icsp_ctx_t* ctx);
 const char* icsp_strerror(int status);
+int icsp_device_count(void);          /* usable HIP devices (0 when there is none or the runtime cannot start) */
 const char* icsp_last_error(const icsp_ctx_t* ctx);   /* text of the last HIP failure on this context */
 
 /* ---- one-call host path: replaces the allintraPrediction / intraPrediction+interPrediction loop of

@@ -57,17 +57,17 @@ DEC = os.path.join(ROOT, "icspcodec_amd", "icsp_dec")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [["--gpus", "2"], ["--gpus", "3", "--hostpack"], ["--EnMultiThread", "2"]])
+@pytest.mark.parametrize("extra", [["--gpus", "2"], ["--gpus", "3", "--hostpack"], ["--EnMultiThread", "2"], ["--EnMultiThread", "4"]])
 def test_cli_multi_shard_path_on_one_gpu(tmp_path, golden_dir, extra):
-    """--gpus N with every shard forced onto device 0 (test hook): closed-GOP shards in their own contexts and threads, one
-    bit-string piece per shard concatenated bit-wise on the host -> the same files as the reference's single run."""
+    """--gpus N / --EnMultiThread N with more shards than devices (shards share devices round-robin): closed-GOP shards in
+    their own contexts and threads, one bit-string piece per shard concatenated bit-wise on the host -> the same files as
+    the reference's single run."""
     n, qp, period = 12, 16, 6                      # 2 GOPs: --gpus 3 is clipped to 2 shards
     clip = clipgen.synth_clip("foremanlike", n)
     fn = clipgen.file_name("foremanlike", n)
     clip.tofile(tmp_path / fn)
-    env = dict(os.environ, ICSP_ENC_SAME_DEVICE="1")
     r = subprocess.run([ENC, "-i", fn, "-n", str(n), "-q", str(qp), "--intraPeriod", str(period)] + extra, cwd=tmp_path,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env)
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 0, r.stdout
     streams = json.load(open(os.path.join(golden_dir, "streams.json")))
     ref = [s for s in streams if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", n, qp, period) and "bin_sha256" in s][0]
