@@ -74,9 +74,12 @@ __constant__ MeTables c_me;
 __device__ unsigned g_spin_timeouts;   // bounded waits that ran out (k_serial_fused); never expected, exposed for the tests
 
 #ifdef ICSP_DIAG
+#ifndef ICSP_DIAG_BLOCK
+#define ICSP_DIAG_BLOCK 0        // which workgroup of the launch is stamped
+#endif
 // Diagnostic build only (tools/diag_intra.hip): per-phase shader-cycle shares of one wave, never in the product build.
 __device__ unsigned long long g_diag[16];
-#define DIAG_DECL unsigned long long dg_t0 = 0, dg_acc[8] = {0,0,0,0,0,0,0,0}; const bool dg_on = (blockIdx.x == 0 && threadIdx.x < 64);
+#define DIAG_DECL unsigned long long dg_t0 = 0, dg_acc[8] = {0,0,0,0,0,0,0,0}; const bool dg_on = (blockIdx.x == ICSP_DIAG_BLOCK && threadIdx.x < 64);
 #define DIAG_START if (dg_on) { __builtin_amdgcn_sched_barrier(0); dg_t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
 #define DIAG_STAMP(n) if (dg_on) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); dg_acc[n] += t_ - dg_t0; dg_t0 = t_; __builtin_amdgcn_sched_barrier(0); }
 #define DIAG_END if (dg_on && (threadIdx.x == 0)) { for (int z_ = 0; z_ < 8; z_++) g_diag[z_] = dg_acc[z_]; g_diag[8] = __builtin_amdgcn_s_memrealtime() - dg_rt0; g_diag[9] = __builtin_amdgcn_s_memtime() - dg_c0; }
