@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(HERE, "libicsp_hip.so")
 SYMBOLS = [
     "icsp_create", "icsp_destroy", "icsp_strerror", "icsp_device_count", "icsp_last_error", "icsp_encode_gop", "icsp_upload",
     "icsp_encode_resident", "icsp_sync", "icsp_download", "icsp_device_view", "icsp_download_debug",
-    "icsp_debug_keep_coef", "icsp_download_coef", "icsp_debug_spin_timeouts", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
+    "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
     "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
 ]
@@ -73,7 +73,6 @@ def load() -> C.CDLL:
         lib.icsp_pack_bits.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_uint64)]
         lib.icsp_bitstream_assemble.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), vp, C.c_size_t,
                                                 C.POINTER(C.c_size_t)]
-        lib.icsp_debug_spin_timeouts.argtypes = [vp, C.POINTER(C.c_uint)]
         lib.icsp_parse_header.argtypes = [vp, C.c_size_t, C.POINTER(Params)]
         lib.icsp_parse_bitstream.argtypes = [vp, C.c_size_t, C.c_int, vp, vp, vp, vp]
         lib.icsp_upload_syntax.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
@@ -227,12 +226,6 @@ class Encoder:
 
     def keep_coef(self, on=True):
         self._chk(self.lib.icsp_debug_keep_coef(self.ctx, int(on)), "icsp_debug_keep_coef")
-
-    def spin_timeouts(self) -> int:
-        """Expired device-side waits since the library was loaded (must be 0)."""
-        c = C.c_uint(0)
-        self._chk(self.lib.icsp_debug_spin_timeouts(self.ctx, C.byref(c)), "icsp_debug_spin_timeouts")
-        return c.value
 
     def upload_syntax(self, first, levels, mpm, mvd):
         lv = np.ascontiguousarray(levels, np.int16); mp = np.ascontiguousarray(mpm, np.uint8); mv = np.ascontiguousarray(mvd, np.int8)

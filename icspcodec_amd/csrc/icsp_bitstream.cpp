@@ -168,6 +168,10 @@ int icsp_parse_header(const uint8_t* bin, size_t nbytes, icsp_params_t* out)
     out->height = bin[5] | (bin[6] << 8); out->width = bin[7] | (bin[8] << 8);
     out->qp_dc = bin[9]; out->qp_ac = bin[10];
     out->intra_period = ((bin[12] | (bin[13] << 8)) & 0x1F80) >> 7;      // DEC:29
+    // the geometry icsp_create accepts; a crafted header must end in a status, not in a giant allocation by the caller
+    if (out->width % 16 || out->height % 16 || out->width < 32 || out->width > 4096 || out->height < 16 || out->height > 2304 ||
+        (out->width / 16) * (out->height / 16) > 8704 || out->qp_dc <= 0 || out->qp_ac <= 0)
+        return ICSP_ERR_UNCORRECT_PARAM;
     return ICSP_OK;
 }
 
@@ -177,7 +181,7 @@ int icsp_parse_bitstream(const uint8_t* bin, size_t nbytes, int n,
     if (!levels || !acflag || !mpm_mode || !mvd) return ICSP_ERR_UNENOUGH_PARAM;
     icsp_params_t p;
     if (int rc = icsp_parse_header(bin, nbytes, &p)) return rc;
-    if (n < 0 || p.width % 16 || p.height % 16 || p.width < 32 || p.height < 16) return ICSP_ERR_UNCORRECT_PARAM;
+    if (n < 0) return ICSP_ERR_UNCORRECT_PARAM;
     const size_t nmb = (size_t)(p.width / 16) * (p.height / 16);
     BitReader r{ bin + 14, (uint64_t)(nbytes - 14) * 8, 0, false };
     for (int f = 0; f < n; f++) {

@@ -50,7 +50,8 @@ int main(int argc, char* argv[])
 
     icsp_params_t p;
     if (icsp_parse_header(bin.data(), bin.size(), &p) != ICSP_OK) { printf("this bin file is not icspCodec file\nerror in readHeader\n"); exit(-1); }
-    if (nframes <= 0) { printf("error in readBlockData\n"); exit(-1); }
+    // a frame needs at least 2 bits per block, so the file size bounds the frame count a header can justify
+    if (nframes <= 0 || (uint64_t)nframes * (p.width / 16) * (p.height / 16) * 12 > (uint64_t)bin.size() * 8) { printf("error in readBlockData\n"); exit(-1); }
     if (atoi(argv[3]) != p.qp_dc || atoi(argv[4]) != p.qp_ac || atoi(argv[5]) != p.intra_period)
         fprintf(stderr, "[note] command-line QPDC/QPAC/intraPeriod differ from the header (%d %d %d); the header is used\n",
                 p.qp_dc, p.qp_ac, p.intra_period);
@@ -74,7 +75,8 @@ int main(int argc, char* argv[])
     const double detime = (double)(clock() - t0) / CLOCKS_PER_SEC;
 
     // checkResultFrames(..., INTRA|INTER, SAVE_YUV)
-    const char* outname = (p.intra_period == 1) ? "check_test_intra_yuv.yuv" : "check_test_inter_yuv.yuv";
+    // header period 0 (what the encoder writes for --intraPeriod 0) is all-intra too
+    const char* outname = (p.intra_period <= 1) ? "check_test_intra_yuv.yuv" : "check_test_inter_yuv.yuv";
     FILE* out = fopen(outname, "wb");
     if (!out) { printf("fail to save yuv\n"); }
     else { fwrite(dec.data(), fsz, nframes, out); fclose(out); }

@@ -71,7 +71,6 @@ struct MeTables {
     int     n_union;
 };
 __constant__ MeTables c_me;
-__device__ unsigned g_spin_timeouts;   // bounded waits that ran out (k_serial_fused); never expected, exposed for the tests
 
 #ifdef ICSP_DIAG
 #ifndef ICSP_DIAG_BLOCK
@@ -106,7 +105,7 @@ struct DevBufs {
     int8_t* mv; uint8_t* imode;       // debug taps / inter-kernel data
     uint32_t* me_ent;                 // [slot][nmb][4] packed (mvx, mvy, next state)
     int* me_flag;                     // [slot] set by k_me<false> when a macroblock of the frame broke out of its walk early
-    int* me_done;                     // [slot] k_serial_fused: macroblocks of the frame whose four-state search is published
+    int* me_done;                     // [slot] k_serial_fused: arrival tickets of a flagged frame's workgroups (0 between launches)
     int16_t* me_sums;                 // [slot][nmb][4][6] residual block sums of a P-frame MB for each search state
     int16_t* dcpred;                  // [slot][nmb][6] DC predictors
     double* coef;                     // optional [slot][nmb][6][64]
@@ -234,6 +233,7 @@ struct icsp_ctx {
     // after other work was queued on `stream` (st_ahead) or when an outside producer uses the stream (always_sync)
     bool s2_dirty, st_ahead, always_sync;
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
+    int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
     int p_groups;                     // GOP groups whose P-step chains run on separate streams
     hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
     hipEvent_t ev_pjoin[kMaxPGroups];
@@ -251,6 +251,20 @@ struct icsp_ctx {
 };
 
 namespace {
+
+// Tuning/diagnostic overrides read by icsp_create (documented in icsp_hip.h).  Unset: *out keeps its default and the result is
+// true; set to a whole number inside [lo, hi]: taken; anything else: false (icsp_create then fails with UNCORRECT_PARAM
+// instead of running in a mode nobody asked for).
+bool env_int(const char* name, int lo, int hi, int* out)
+{
+    const char* v = getenv(name);
+    if (!v) return true;
+    char* end = nullptr;
+    const long k = strtol(v, &end, 10);
+    if (end == v || *end != 0 || k < lo || k > hi) return false;
+    *out = (int)k;
+    return true;
+}
 
 void build_me_tables(MeTables& t)
 {
@@ -282,7 +296,11 @@ template <typename F> int launch_timed(icsp_ctx* ctx, int kernel, hipStream_t st
     if (ctx->ev_pool.empty() && ctx->ev_pending.size() >= 8192) collect_profile(ctx);     // keeps the list bounded (this one blocks)
     EvPair e;
     if (!ctx->ev_pool.empty()) { e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
-    else { if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) return ICSP_ERR_HIP; }
+    else {
+        // no event to be had: the launch itself must still happen, it just goes untimed
+        if (hipEventCreate(&e.a) != hipSuccess) { f(); return 0; }
+        if (hipEventCreate(&e.b) != hipSuccess) { hipEventDestroy(e.a); f(); return 0; }
+    }
     e.kernel = kernel;
     hipEventRecord(e.a, st);
     f();
@@ -306,7 +324,7 @@ int collect_profile(icsp_ctx* ctx)
 
 int check_range(icsp_ctx* ctx, int first, int n)
 {
-    if (first < 0 || n < 0 || first + n > ctx->max_frames) return ICSP_ERR_RANGE;
+    if (first < 0 || n < 0 || (long long)first + n > ctx->max_frames) return ICSP_ERR_RANGE;
     return 0;
 }
 
@@ -385,15 +403,17 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             FrameSel fs{ first + g0 * L + i, L, Gi };
             const long long nmbs = (long long)Gi * g.nmb, nblk = nmbs * 6;
             const size_t serial_lds = ((size_t)g.nmb * 15 + 15) & ~(size_t)15;
-            // small frames, not too many of them: the four-state search rides in the serial kernel's launch (one kernel
-            // boundary less per step); else two launches, the serial one with 1024 threads for its staging loops
-            const bool fused = g.nmb < 2048 && Gi <= 1024 && !ctx->no_fuse;
+            // small frames: the four-state search rides in the serial kernel's launch (one kernel boundary less per step;
+            // nobody waits inside that launch, see k_serial_fused); else two launches, the serial one with 1024 threads for
+            // its staging loops
+            const bool fused = g.nmb < 2048 && !ctx->no_fuse;
+            const int wpf4 = (g.nmb + 3) / 4, wpf16 = (g.nmb + 15) / 16;
             launch_timed(ctx, ICSP_K_ME, sk, [&] {
-                hipLaunchKernelGGL((k_me<false, 4>), dim3((unsigned)((nmbs + 3) / 4)), dim3(256), 0, sk, g, fs, b);
-                if (!fused) hipLaunchKernelGGL((k_me<true, 16>), dim3((unsigned)((nmbs + 15) / 16)), dim3(1024), 0, sk, g, fs, b);
+                hipLaunchKernelGGL((k_me<false, 4>), dim3((unsigned)((long long)Gi * wpf4)), dim3(256), 0, sk, g, fs, b, wpf4);
+                if (!fused) hipLaunchKernelGGL((k_me<true, 16>), dim3((unsigned)((long long)Gi * wpf16)), dim3(1024), 0, sk, g, fs, b, wpf16);
             });
             launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
-                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3((unsigned)(Gi + (nmbs + 3) / 4)), dim3(256), serial_lds, sk, g, fs, b, Gi);
+                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3((unsigned)(Gi + (long long)Gi * wpf4)), dim3(256), serial_lds, sk, g, fs, b, Gi, wpf4);
                 else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
             });
             launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, sk, g, fs, b, 0, 6, 1); });
@@ -467,8 +487,7 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     // waves x 128 VGPRs so two workgroups share a CU and every frame of the batch is in flight at once (measured on
     // 300 CIF frames: 0.45 ms vs 0.57 ms).
     const int need = ctx->intra_waves;
-    const char* force = getenv("ICSP_INTRA_NW");
-    const int nw = force ? atoi(force) : (G > ctx->n_cu ? (need < 8 ? need : 8) : need);
+    const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : (G > ctx->n_cu ? (need < 8 ? need : 8) : need);
     if (nw <= 2)       hipLaunchKernelGGL((k_intra_luma32<2, 1>), dim3(G), dim3(128), 0, st, g, fs, b);
     else if (nw <= 4)  hipLaunchKernelGGL((k_intra_luma32<4, 1>), dim3(G), dim3(256), 0, st, g, fs, b);
     else if (nw <= 6)  hipLaunchKernelGGL((k_intra_luma32<6, 3>), dim3(G), dim3(384), 0, st, g, fs, b);
@@ -543,10 +562,13 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0;
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
-    ctx->no_fuse = getenv("ICSP_NO_FUSE") != nullptr;
+    int no_fuse = 0;
+    ctx->force_intra_nw = 0;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured: 2 groups +7 %, 3 no better, more streams than hardware queues collapse
-    if (const char* v = getenv("ICSP_P_GROUPS")) { int k = atoi(v); if (k >= 1 && k <= kMaxPGroups) ctx->p_groups = k; }
+    if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) ||
+        !env_int("ICSP_INTRA_NW", 2, 16, &ctx->force_intra_nw)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
+    ctx->no_fuse = no_fuse != 0;
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
     auto fail = [&](int code, const char* what, hipError_t e) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); icsp_destroy(ctx); return code; };
     hipError_t e;
@@ -795,16 +817,6 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first, int n, double* coef)
     join_s2(ctx);
     HIPCHK(hipMemcpyAsync(coef, ctx->b.coef + (size_t)first * per, (size_t)n * per * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    return ICSP_OK;
-}
-
-int icsp_debug_spin_timeouts(icsp_ctx_t* ctx, unsigned* count)
-{
-    if (!ctx || !count) return ICSP_ERR_UNENOUGH_PARAM;
-    HIPCHK(hipSetDevice(ctx->device));
-    join_s2(ctx);
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_spin_timeouts), sizeof(unsigned)));
     return ICSP_OK;
 }
 

@@ -22,6 +22,12 @@
  * Errors: every function returns 0 (= reference SUCCESS, ICSP_Codec_Encoder.h:33-39) or a positive
  * icsp_status code; nothing calls exit().  There is NO CPU fallback: without a usable HIP device
  * icsp_create fails with ICSP_ERR_NO_DEVICE.
+ * Environment (read once by icsp_create; meant for tests and tuning, results are identical in every setting; a value
+ * that is not a whole number in the stated range makes icsp_create fail with ICSP_ERR_UNCORRECT_PARAM):
+ *   ICSP_NO_FUSE   0|1   1: a P step's four-state motion search and the per-frame serial kernel run as two launches instead of one
+ *   ICSP_P_GROUPS  1..3  number of GOP groups whose P-step kernel chains run on separate streams (default 2)
+ *   ICSP_INTRA_NW  2..16 waves per workgroup of the intra luma kernel (rounded up to a built variant: 2, 4, 6, 8, 11, 16;
+ *                        default: from the frame width and the batch size)
  * Threading: one context per device; calls on one context must be serialised by the caller; distinct
  * contexts are independent (the host GOP dispatcher uses one thread per GPU, the analogue of
  * encoding_thread, ENC:186-213).
@@ -92,9 +98,6 @@ int icsp_download_debug(icsp_ctx_t* ctx, int first_frame, int n, int8_t* mv, uin
 /* When enabled (before encoding), forward-DCT coefficients before DC prediction/quantisation are kept:
  * double[n][nMB][6][64], row-major [v][u] (DCT_block output, ENC:2685-2749).  Costs 8x the level store. */
 int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
-/* Number of bounded device-side waits that expired since the library was loaded (a flagged frame's serial workgroup waits
- * for that frame's four-state search inside one launch).  Always 0 unless something is broken; syncs the context. */
-int icsp_debug_spin_timeouts(icsp_ctx_t* ctx, unsigned* count);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
 
 /* ---- per-kernel timing with HIP events on the launch stream ---------------------------------- */

@@ -36,7 +36,6 @@ def test_sequence_matches_oracle(name, n, q, period):
     clip = clipgen.synth_clip(name, n)
     enc = capi.Encoder(W, H, q, q, period, max_frames=n)
     got = enc.encode(clip)
-    assert enc.spin_timeouts() == 0              # the fused launch's bounded wait never runs out
     enc.close()
     want = po.encode_sequence(clip, W, H, q, q, period)
     _cmp(got, want, f"{name} n={n} q={q} p={period}: ")
@@ -152,15 +151,21 @@ def test_hd_1088p_config5_geometry():
     _cmp(got, po.encode_sequence(clip, w, h, 16, 16, 3, nthreads=3), "1088p: ")
 
 
-def test_many_small_gops_takes_the_two_launch_path():
-    """More than 1024 GOPs in one call: the per-step launch falls back from k_serial_fused to k_me<true> + k_frame_serial
-    (its serial workgroups must never be able to fill the device while they wait).  Tiny frames, 2200 of them, GOPs of 2;
-    a repeated frame inside some GOPs raises the early-break flags."""
+@pytest.mark.parametrize("env", [{}, {"ICSP_NO_FUSE": "1"}, {"ICSP_P_GROUPS": "1"}], ids=["fused", "two-launch", "one-group"])
+def test_many_small_gops_one_call(env):
+    """1100 GOPs in one call (tiny frames, 2200 of them, GOPs of 2; a repeated frame inside every fourth GOP raises the
+    early-break flags): the fused P step (k_serial_fused: per-frame serial workgroups + four-state search, last arriver runs
+    the serial body), the same as two launches (ICSP_NO_FUSE=1: k_me<true,16> + k_frame_serial), and one GOP group."""
     w, h, n = 64, 48, 2200
     base = clipgen.synth_clip("stefanlike", 40, width=w, height=h)
     clip = np.concatenate([base] * (n // 40))
     clip[1::8] = clip[0::8]                          # every fourth GOP: P frame identical to its I frame
-    enc = capi.Encoder(w, h, 16, 16, 2, max_frames=n)
+    os.environ.update(env)
+    try:
+        enc = capi.Encoder(w, h, 16, 16, 2, max_frames=n)
+    finally:
+        for k in env:
+            del os.environ[k]
     got = enc.encode(clip)
     bs = enc.pack_bitstream(0, n)
     enc.close()

@@ -23,17 +23,14 @@ def run(name, n, q, period, reps, w=352, h=288):
         elif hsh != ref:
             print(f"MISMATCH {name} n={n} q={q} p={period} rep={r}")
             return False
-    to = enc.spin_timeouts()
     enc.close()
-    if to:
-        print(f"SPIN TIMEOUTS {to}"); return False
     print(f"ok {name} {w}x{h} n={n} q={q} p={period} x{reps}: {ref[:16]}")
     return True
 
 ok = True
 ok &= run("foremanlike", 300, 16, 0, 25)
 ok &= run("stefanlike", 300, 8, 10, 25)
-ok &= run("staticlike", 300, 1, 6, 40)      # every frame flagged: the fused kernel's cross-workgroup wait on every P step
+ok &= run("staticlike", 300, 1, 6, 40)      # every frame flagged: the fused kernel's last-arriver hand-off on every P step
 ok &= run("staticlike", 60, 16, 3, 40)
 ok &= run("mobilelike", 64, 16, 4, 10, 704, 576)
 ok &= run("tablelike", 6, 16, 3, 5, 1920, 1088)
