@@ -1,22 +1,32 @@
 #!/usr/bin/env python3
 """bench.py — CIF encode throughput of the HIP hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the per-macroblock encode loop over one resident batch: BASELINE.json configs[1], i.e. a
-300-frame CIF clip, all-intra, QP 16 (synthetic `foremanlike`, the bundled clips are absent from the reference
-checkout).  Inputs are uploaded to HBM before the timed region.  With N GPUs every rank encodes its own 300-frame
-shard (closed GOPs / independent frames shard with no collective: weak scaling); value = frames of all ranks / max
-rank time.  Rank 0 prints ONE JSON line.  Secondary figures in the same line: the IPPP workload (configs[2]:
-`stefanlike` 300 f, --intraPeriod 10, QP 8), reconstructed PSNR, the per-kernel HIP-event timing and roofline of the
-dominant kernel, the CPU baseline (the reference's own --EnMultiThread path, timed on this box's host cores), the device
-bit packer (`device_pack`) and the device decoder (`decode`).
+N > 1 without WORLD_SIZE in the environment: this process starts N ranks itself (a child `python -m torch.distributed.run
+... bench.py --gpus N ...`, before anything here touches the GPU) and exits with the child's code; started BY
+torch.distributed.run (the driver's way) it is one rank.  One rank per GPU, RCCL only for the barrier and the reductions of
+the timing: closed GOPs / independent frames shard with no data-path collective.
+
+A "step" is one pass of the per-macroblock encode loop over one resident batch.  `value` is BASELINE.json configs[1]: a
+300-frame CIF clip, all-intra, QP 16 (synthetic `foremanlike`; the bundled clips are absent from the reference checkout),
+every rank its own 300-frame shard (weak scaling), inputs uploaded to HBM before the timed region.  Rank 0 prints ONE JSON
+line.  In the same line:
+  ippp       configs[2]: `stefanlike` 300 f, --intraPeriod 10, QP 8 (motion search + compensation), weak, like `value`
+  config4    configs[3]: the twelve CIF clips (3390 frames, 339 closed GOPs), --intraPeriod 10, QP 16, ONE batch whose GOPs
+             are sharded over the ranks (strong scaling); `all_intra_loaded`: the same 3390 frames all-intra (a loaded chip)
+  config5    configs[4]: 1920x1088, --intraPeriod 30, 3000 frames = 100 GOPs sharded over the ranks (strong scaling)
+  roofline / kernels_roofline, cpu_baseline (the reference's own --EnMultiThread path timed on this box), device_pack,
+  decode, e2e (the icsp_enc program: file -> .bin + test_yuv.yuv), PSNR.
+Every leg's output is checked (outside the timed region) against reference hashes or the oracle.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -32,23 +42,44 @@ P = W * H
 NMB = (W // 16) * (H // 16)
 NFRAMES = 300
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
+# un-fused fp64 vector peak: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 39.3 T instructions-lanes/s; a fused multiply-add
+# counts two flops (78.6 Tflop/s, the spec figure), a separate multiply or add one.  (Not in the guide; derived from the spec.)
+FP64_VALU_PEAK_GOPS = 256 * 4 * 16 * 2.4
 SETTLE_PASSES = 100            # untimed passes (about 40 ms) before the W warmup steps of every timed leg: the GPU clock ramps
                                # up over the first tens of milliseconds of load, which would make the figure depend on W and K
 
 # Algorithmic HBM bytes per CIF frame: every input/reference/output byte crosses once.
-#   whole I frame: read 1.5P, write recon 1.5P + levels 3P (int16) + side info 10 B/MB (acflag 6, mpm 4)
-#   k_intra_luma's share (luma only): read P, write recon P + levels 2P + 8 B/MB (acflag 4, mpm 4)
 BYTES_I_FRAME_READ = P * 3 // 2
-BYTES_I_FRAME_TOTAL = P * 3 // 2 + P * 3 // 2 + 3 * P + 10 * NMB
-BYTES_INTRA_LUMA_KERNEL = P + P + 2 * P + 8 * NMB
+BYTES_I_FRAME_TOTAL = P * 3 // 2 + P * 3 // 2 + 3 * P + 10 * NMB       # + recon + int16 levels + acflag/mpm
+BYTES_INTRA_LUMA_KERNEL = P + P + 2 * P + 8 * NMB                      # luma only: read P, write recon P + levels 2P + 8 B/MB
 BYTES_P_FRAME_READ = 3 * P
+# per P frame and kernel: k_me reads cur luma+chroma 1.5P + reference 1.5P, writes 64 B/MB; k_frame_serial moves 84 B/MB;
+# k_residual reads cur 1.5P + prediction 1.5P, writes recon 1.5P + levels 3P + 8 B/MB
+BYTES_P_KERNEL = {"k_me": 3 * P + 64 * NMB, "k_frame_serial": 84 * NMB, "k_residual": 3 * P + P * 3 // 2 + 3 * P + 8 * NMB}
+
+CLIPS12 = ["akiyolike", "childrenlike", "coastguardlike", "containerlike", "footballlike", "foremanlike", "hallmonitorlike",
+           "mobilelike", "motherdaughterlike", "newslike", "stefanlike", "tablelike"]
 
 
-def cpu_baseline(rank: int):
-    """Reference --EnMultiThread path (oracle/_ref/icsp_ref, built from /root/reference) on a 300-frame all-I clip;
-    falls back to the oracle's GOP thread pool ("port") when the reference binary did not travel."""
-    if rank != 0:
-        return None
+# ------------------------------------------------------------------------------------------------ launcher
+def spawn_ranks(a, argv):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child job.  Nothing in this process has touched the
+    GPU (no HIP call, not even torch.cuda.is_available()), and the child is a fresh process, never an exec of this one."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline():
+    """Reference --EnMultiThread path (oracle/_ref/icsp_ref, built from /root/reference) on a 300-frame all-I clip; falls
+    back to the oracle's GOP thread pool ("port") when the reference binary did not travel.  Rank 0 at N=1 only."""
     from icspcodec_amd import clipgen
     from oracle import pyoracle as po
     cores = os.cpu_count() or 1
@@ -77,24 +108,31 @@ def cpu_baseline(rank: int):
                 dt = time.perf_counter() - t0
                 if r.returncode == 0 and r1.returncode == 0:
                     return {"value": round(NFRAMES / dt, 2), "unit": "frames/s", "cores": threads, "kind": "reference",
-                            "sample": f"reference binary (g++ -O2) whole process incl. file load, foremanlike 300 f all-I QP16, "
-                                      f"--intraPeriod 1 --EnMultiThread {threads} (its queue races beyond a few threads); "
-                                      f"single-thread --intraPeriod 0: {NFRAMES / dt1:.2f} frames/s; host has {cores} logical cores",
+                            "single_thread": {"value": round(NFRAMES / dt1, 2), "unit": "frames/s", "cores": 1,
+                                              "sample": "reference binary, --intraPeriod 0, no thread pool (BASELINE configs[0])"},
+                            "sample": f"reference binary (g++ -O2) whole process incl. file load and (single-thread) bitstream writing, "
+                                      f"foremanlike 300 f all-I QP16, --intraPeriod 1 --EnMultiThread {threads} (its queue races "
+                                      f"beyond a few threads); host has {cores} logical cores",
                             "port_all_cores": port}
     return port
 
 
+# ------------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--legs", default="ippp,config4,config5,e2e", help="secondary legs to run (comma list; '' = none)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a, sys.argv[1:]))
+    legs = {x for x in a.legs.split(",") if x}
 
     import torch
     import torch.distributed as dist
-    from icspcodec_amd import capi, clipgen
+    from icspcodec_amd import capi, clipgen, shard
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,6 +155,14 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def reduce(x, op):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+    ranks_seen = int(reduce(1.0, dist.ReduceOp.SUM)) if world > 1 else 1
 
     def timed(enc, n, steps, warmup, dominant):
         """K timed steps (HIP events only around the dominant kernel, none if it is None), then three untimed passes with
@@ -141,13 +187,22 @@ def main():
         for _ in range(3):
             enc.encode_resident(0, n)
         enc.sync()
-        prof = {k: (v[0] / 3.0, v[1]) for k, v in enc.profile_get().items()}
+        prof = {k: (v[0] / 3.0, v[1] // 3) for k, v in enc.profile_get().items()}      # (ms per pass, launches per pass)
         enc.profile(False)
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt, prof, (dom_ms, dom_n)
+        return reduce(dt, dist.ReduceOp.MAX), prof, (dom_ms, dom_n)
+
+    def timed_passes(enc, n, passes):
+        """Big batches: two warm passes, then `passes` timed ones between barriers; max over ranks."""
+        for _ in range(2):
+            enc.encode_resident(0, n)
+        enc.sync()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(passes):
+            enc.encode_resident(0, n)
+        enc.sync()
+        barrier()
+        return reduce(time.perf_counter() - t0, dist.ReduceOp.MAX) / passes
 
     # ---- primary: configs[1] all-intra QP16, each rank its own 300-frame shard of the synthetic sequence
     clip = clipgen.synth_clip("foremanlike", NFRAMES, first_frame=rank * NFRAMES)
@@ -156,6 +211,12 @@ def main():
     dt, prof, (ms_ai, n_ai) = timed(enc, NFRAMES, a.steps, a.warmup, "k_intra_luma")
     recon = enc.download(0, NFRAMES, what=("recon",))["recon"]
     psnr_ai = clipgen.psnr_y(clip, recon, W, H)
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "streams.json")))
+    parity = {}
+    if rank == 0:       # rank 0's shard is the clip the reference CLI was run on: same recon bytes, same .bin
+        ref = next(s for s in golden if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", 300, 16, 0) and "bin_sha256" in s)
+        parity["configs1_recon_sha_equals_reference"] = hashlib.sha256(recon.tobytes()).hexdigest() == ref["recon_sha256"]
+        parity["configs1_bin_sha_equals_reference"] = hashlib.sha256(enc.pack_bitstream(0, NFRAMES)).hexdigest() == ref["bin_sha256"]
     # PCIe-inclusive (host buffers in, host results out) — reported, never `value`
     t0 = time.perf_counter()
     enc.encode(clip)
@@ -192,45 +253,204 @@ def main():
     kern_ms = ms_ai / max(n_ai, 1)
     achieved = BYTES_INTRA_LUMA_KERNEL * NFRAMES / (kern_ms * 1e-3) / 1e9 if n_ai else 0.0
 
-    # ---- secondary: configs[2] IPPP, stefanlike --intraPeriod 10 QP8 (ME + MC path)
-    clip2 = clipgen.synth_clip("stefanlike", NFRAMES, first_frame=rank * NFRAMES)
-    enc2 = capi.Encoder(W, H, 8, 8, 10, device=local, max_frames=NFRAMES)
-    enc2.upload(clip2)
-    steps2 = max(2, a.steps // 2)
-    dt2, prof2, _ = timed(enc2, NFRAMES, steps2, min(a.warmup, 2), None)      # no events inside this timed region
-    recon2 = enc2.download(0, NFRAMES, what=("recon",))["recon"]
-    psnr_ip = clipgen.psnr_y(clip2, recon2, W, H)
-    dec_ip_fps = decode_fps(enc2)
-    enc2.close()
-    fps2 = world * NFRAMES * steps2 / dt2
+    # ---- configs[2] IPPP, stefanlike --intraPeriod 10 QP8 (ME + MC path), weak like the primary
+    ippp = None
+    if "ippp" in legs:
+        clip2 = clipgen.synth_clip("stefanlike", NFRAMES, first_frame=rank * NFRAMES)
+        enc2 = capi.Encoder(W, H, 8, 8, 10, device=local, max_frames=NFRAMES)
+        enc2.upload(clip2)
+        steps2 = max(2, a.steps // 2)
+        dt2, prof2, _ = timed(enc2, NFRAMES, steps2, min(a.warmup, 2), None)      # no events inside this timed region
+        recon2 = enc2.download(0, NFRAMES, what=("recon",))["recon"]
+        psnr_ip = clipgen.psnr_y(clip2, recon2, W, H)
+        if rank == 0:
+            ref = next(s for s in golden if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("stefanlike", 300, 8, 10))
+            parity["configs2_recon_sha_equals_reference"] = hashlib.sha256(recon2.tobytes()).hexdigest() == ref["recon_sha256"]
+        dec_ip_fps = decode_fps(enc2)
+        enc2.close()
+        fps2 = world * NFRAMES * steps2 / dt2
+        read_mean_ip = (BYTES_I_FRAME_READ + 9 * BYTES_P_FRAME_READ) / 10.0
+        kr = {}
+        for k, per_frame in BYTES_P_KERNEL.items():
+            ms, nl = prof2.get(k, (0.0, 0))
+            if nl:
+                frames_per_launch = 270.0 / nl                 # 270 P frames per pass, spread over the launches of that kernel
+                gbs = per_frame * frames_per_launch / (ms / nl * 1e-3) / 1e9
+                kr[k] = {"avg_launch_us": round(ms / nl * 1e3, 2), "frames_per_launch": round(frames_per_launch, 1),
+                         "algorithmic_bytes_per_launch": int(per_frame * frames_per_launch), "achieved_GBps": round(gbs, 1),
+                         "hbm_frac": round(gbs / HBM_PEAK_GBS, 5)}
+        ippp = {"workload": "stefanlike_cif 300f, --intraPeriod 10, QP=8 (BASELINE configs[2]), per GPU", "value": round(fps2, 1),
+                "unit": "frames/s", "ms_per_step": round(dt2 / steps2 * 1e3, 4), "psnr_y_db": round(psnr_ip, 4),
+                "read_roofline_frac": round(fps2 / world * read_mean_ip / 1e9 / HBM_PEAK_GBS, 5),
+                "kernels_ms_per_step": {k: round(v[0], 4) for k, v in prof2.items() if v[1]},
+                "launches_per_step": {k: v[1] for k, v in prof2.items() if v[1]},
+                "kernels_roofline": kr, "decode_fps": round(dec_ip_fps, 1),
+                "kernels_note": "HIP-event time summed over launches (the events themselves cost a few us per launch); the GOP "
+                                "groups' P-step chains and the I-frame chroma run on concurrent streams, so the sum exceeds ms_per_step"}
 
-    cpu = None if (a.no_cpu or world > 1) else cpu_baseline(rank)      # CPU baseline: rank 0 at N=1 only
+    # ---- configs[3]: the twelve clips as ONE batch of 339 closed GOPs, sharded over the ranks (strong scaling)
+    config4 = None
+    if "config4" in legs:
+        from oracle import pyoracle as po
+        units = []                                                     # (clip, first frame of the GOP, frames)
+        for name in CLIPS12:
+            n = clipgen.CLIP_CLASSES[name]["nframes"]
+            units += [(name, f, min(10, n - f)) for f in range(0, n, 10)]
+        per = len(units) // world
+        lo = rank * per + min(rank, len(units) % world)
+        mine = units[lo: lo + per + (1 if rank < len(units) % world else 0)]
+        cache, parts = {}, []
+        for name, f, cnt in mine:
+            if name not in cache:
+                cache = {name: clipgen.synth_clip(name)}                # whole clip once, GOPs are slices of it
+            parts.append(cache[name][f: f + cnt])
+        batch = np.concatenate(parts)
+        nloc, ntot = batch.shape[0], sum(u[2] for u in units)
+        enc4 = capi.Encoder(W, H, 16, 16, 10, device=local, max_frames=nloc)
+        enc4.upload(batch)
+        sec = timed_passes(enc4, nloc, 5)
+        rec4 = enc4.download(0, nloc, what=("recon",))["recon"]
+        ok4 = True
+        if world == 1:        # whole clips on this rank: the reference CLI's recon hashes (tests/golden/streams.json)
+            pos = 0
+            for name in CLIPS12:
+                n = clipgen.CLIP_CLASSES[name]["nframes"]
+                ref = next(s for s in golden if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == (name, n, 16, 10) and "bin_sha256" in s)
+                ok4 &= hashlib.sha256(rec4[pos: pos + n].tobytes()).hexdigest() == ref["recon_sha256"]
+                pos += n
+        else:                 # a rank holds runs of GOPs: its first and last GOP against the oracle
+            for sl in (slice(0, mine[0][2]), slice(nloc - mine[-1][2], nloc)):
+                ok4 &= np.array_equal(rec4[sl], po.encode_sequence(batch[sl], W, H, 16, 16, 10)["recon"])
+        ok4 = reduce(1.0 if ok4 else 0.0, dist.ReduceOp.MIN) == 1.0 if world > 1 else ok4
+        enc4.close()
+        # the same frames all-intra: every CU busy (the throughput regime of the intra kernels)
+        enc4i = capi.Encoder(W, H, 16, 16, 0, device=local, max_frames=nloc)
+        enc4i.upload(batch)
+        sec_i = timed_passes(enc4i, nloc, 5)
+        enc4i.close()
+        config4 = {"workload": "12 CIF clips (11 x 300 f + 1 x 90 f = 3390 frames, 339 closed GOPs), --intraPeriod 10, QP=16, one "
+                               "batch sharded by GOP over the ranks (BASELINE configs[3])", "scaling": "strong",
+                   "value": round(ntot / sec, 1), "unit": "frames/s", "ms_per_pass": round(sec * 1e3, 3), "frames": ntot,
+                   "recon_equals_reference": bool(ok4),
+                   "read_roofline_frac": round(ntot / sec * (BYTES_I_FRAME_READ + 9 * BYTES_P_FRAME_READ) / 10.0 / 1e9 / HBM_PEAK_GBS / world, 5),
+                   "all_intra_loaded": {"value": round(ntot / sec_i, 1), "unit": "frames/s", "ms_per_pass": round(sec_i * 1e3, 3),
+                                        "read_roofline_frac": round(ntot / sec_i * BYTES_I_FRAME_READ / 1e9 / HBM_PEAK_GBS / world, 5),
+                                        "rw_roofline_frac": round(ntot / sec_i * BYTES_I_FRAME_TOTAL / 1e9 / HBM_PEAK_GBS / world, 5)}}
+        del batch, rec4, parts, cache
+
+    # ---- configs[4]: 1920x1088, --intraPeriod 30, 3000 frames = 100 GOPs sharded over the ranks (strong scaling)
+    config5 = None
+    if "config5" in legs:
+        from oracle import pyoracle as po
+        w5, h5, L5, ngop5 = 1920, 1088, 30, 100
+        fsz5 = w5 * h5 * 3 // 2
+        per = ngop5 // world
+        g_lo = rank * per + min(rank, ngop5 % world)
+        g_n = per + (1 if rank < ngop5 % world else 0)
+        # "CIF-tiled macroblock grid": a 1088p frame is the CIF frame tiled; GOP g shows clip (g mod 4), so four distinct GOPs
+        srcs = ["foremanlike", "stefanlike", "mobilelike", "akiyolike"]
+
+        def hd_gop(name):
+            c = clipgen.synth_clip(name, L5)
+            out = np.empty((L5, fsz5), np.uint8)
+            for i in range(L5):
+                y = c[i, :P].reshape(H, W); cb = c[i, P: P + P // 4].reshape(H // 2, W // 2); cr = c[i, P + P // 4:].reshape(H // 2, W // 2)
+                out[i, : w5 * h5] = np.tile(y, (4, 6))[:h5, :w5].ravel()
+                out[i, w5 * h5: w5 * h5 * 5 // 4] = np.tile(cb, (4, 6))[: h5 // 2, : w5 // 2].ravel()
+                out[i, w5 * h5 * 5 // 4:] = np.tile(cr, (4, 6))[: h5 // 2, : w5 // 2].ravel()
+            return out
+        gops = {nm: hd_gop(nm) for nm in {srcs[(g_lo + g) % 4] for g in range(g_n)}}
+        enc5 = capi.Encoder(w5, h5, 16, 16, L5, device=local, max_frames=g_n * L5)
+        for g in range(g_n):
+            enc5.upload(gops[srcs[(g_lo + g) % 4]], first=g * L5)
+        sec5 = timed_passes(enc5, g_n * L5, 2)
+        # check (outside the timed region): one resident GOP of each distinct content against the oracle's GOP thread pool
+        first_of = {}
+        for g in range(g_n):
+            first_of.setdefault((g_lo + g) % 4, g)
+        check = sorted(first_of.items())[: (4 if world == 1 else 1)]
+        want = po.encode_sequence(np.concatenate([gops[srcs[k]] for k, _ in check]), w5, h5, 16, 16, L5, nthreads=len(check))["recon"]
+        ok5 = True
+        for j, (k, g) in enumerate(check):
+            ok5 &= np.array_equal(enc5.download(g * L5, L5, what=("recon",))["recon"], want[j * L5: (j + 1) * L5])
+        ok5 = reduce(1.0 if ok5 else 0.0, dist.ReduceOp.MIN) == 1.0 if world > 1 else ok5
+        enc5.close()
+        n5 = ngop5 * L5
+        rd5 = (w5 * h5 * 3 // 2 + 29 * 3 * w5 * h5) / 30.0
+        config5 = {"workload": "1920x1088 (CIF-tiled macroblock grid), 3000 frames = 100 closed GOPs of 30, QP=16, sharded by GOP over "
+                               "the ranks (BASELINE configs[4]; 1080 is not a multiple of 16)", "scaling": "strong",
+                   "value": round(n5 / sec5, 1), "unit": "frames/s", "ms_per_pass": round(sec5 * 1e3, 2), "frames": n5,
+                   "cif_equivalent_fps": round(n5 / sec5 * (w5 * h5) / P, 1), "recon_equals_oracle": bool(ok5),
+                   "read_roofline_frac": round(n5 / sec5 * rd5 / 1e9 / HBM_PEAK_GBS / world, 5)}
+        del gops
+
+    # ---- the host program end to end: file -> .bin + test_yuv.yuv (rank 0, N = 1 only)
+    e2e = None
+    enc_bin = os.path.join(ROOT, "icspcodec_amd", "icsp_enc")
+    if "e2e" in legs and world == 1 and os.path.exists(enc_bin):
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as tmp:
+            path = os.path.join(tmp, clipgen.file_name("foremanlike", NFRAMES))
+            clip.tofile(path)
+            t0 = time.perf_counter()
+            r = subprocess.run([enc_bin, "-i", path, "-n", str(NFRAMES), "-q", "16", "--intraPeriod", "0"], cwd=tmp, stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT)
+            wall = time.perf_counter() - t0
+            out = r.stdout.decode(errors="replace")
+            e2e = {"wall_fps_incl_process_start_and_hip_init": round(NFRAMES / wall, 1), "rc": r.returncode}
+            for line in out.splitlines():
+                if line.startswith("[icsp_enc]"):
+                    try:
+                        e2e.update(json.loads(line[len("[icsp_enc]"):]))
+                    except Exception:
+                        pass
+            ref = next(s for s in golden if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", 300, 16, 0) and "bin_sha256" in s)
+            binf = [f for f in os.listdir(tmp) if f.endswith(".bin")]
+            e2e["bin_equals_reference"] = bool(binf) and hashlib.sha256(open(os.path.join(tmp, binf[0]), "rb").read()).hexdigest() == ref["bin_sha256"]
+            ry = os.path.join(tmp, "test_yuv.yuv")
+            e2e["recon_equals_reference"] = os.path.exists(ry) and hashlib.sha256(open(ry, "rb").read()).hexdigest() == ref["recon_sha256"]
+
+    cpu = None if (a.no_cpu or world > 1 or rank != 0) else cpu_baseline()      # CPU baseline: rank 0 at N=1 only
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return
 
-    traffic = None
+    traffic, pmc = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_intra_luma_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("k_intra_luma_bytes_per_launch")
+            pmc = tj.get("k_intra_luma_sq")
         except Exception:
             traffic = None
-    read_mean_ip = (BYTES_I_FRAME_READ + 9 * BYTES_P_FRAME_READ) / 10.0
+    roof = {"bound": "hbm", "kernel": "k_intra_luma", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "algorithmic_bytes_per_launch": BYTES_INTRA_LUMA_KERNEL * NFRAMES, "avg_launch_ms": round(kern_ms, 4),
+            "whole_frame_read_frac": round(fps / world * BYTES_I_FRAME_READ / 1e9 / HBM_PEAK_GBS, 5),
+            "whole_frame_rw_frac": round(fps / world * BYTES_I_FRAME_TOTAL / 1e9 / HBM_PEAK_GBS, 5),
+            "limiter": "the contract's roofline is HBM; what actually limits this kernel is the 114-step dependency chain of a CIF "
+                       "frame and vector-instruction issue on the CUs that carry two frames (DESIGN.md §5), see fp64_valu_frac"}
+    if pmc and kern_ms > 0:
+        # executed fp64 vector instructions (rocprofv3 SQ counters, profiles/) x 64 lanes / launch time vs the un-fused peak
+        ops = pmc.get("fp64_valu_insts_per_launch")
+        if ops:
+            roof["fp64_valu_frac"] = round(ops * 64 / (kern_ms * 1e-3) / 1e9 / FP64_VALU_PEAK_GOPS, 4)
+            roof["fp64_valu_peak_Gops"] = round(FP64_VALU_PEAK_GOPS, 1)
+            roof["fp64_valu_source"] = pmc.get("source")
     line = {
-        "metric": "CIF encode fps (all-intra QP=16; IPPP alongside in `ippp`)", "value": round(fps, 1), "unit": "frames/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 4),
+        "metric": "CIF encode fps, resident encode loop (all-intra QP=16; IPPP and the 8-GPU workloads alongside)", "value": round(fps, 1),
+        "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "foremanlike_cif 352x288 300f, --intraPeriod 0 (all-intra), QP=16, per GPU (BASELINE configs[1])",
-                   "frames_per_step_per_gpu": NFRAMES, "parallelism": f"frame/GOP shards over {world} GPU(s), no collectives"},
-        "roofline": {"bound": "hbm", "kernel": "k_intra_luma", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": BYTES_INTRA_LUMA_KERNEL * NFRAMES, "avg_launch_ms": round(kern_ms, 4),
-                     "whole_frame_read_frac": round(fps / world * BYTES_I_FRAME_READ / 1e9 / HBM_PEAK_GBS, 5),
-                     "whole_frame_rw_frac": round(fps / world * BYTES_I_FRAME_TOTAL / 1e9 / HBM_PEAK_GBS, 5)},
+                   "frames_per_step_per_gpu": NFRAMES, "parallelism": f"frame/GOP shards over {world} GPU(s), no collectives",
+                   "timed_region": "resident transform/prediction kernels of the encode loop; entropy packing, PCIe and file I/O are "
+                                   "reported separately (device_pack, e2e) and are part of cpu_baseline's whole-process figure"},
+        "roofline": roof,
         "cpu_baseline": cpu,
+        "parity": parity,
         "kernels_ms_per_step": {k: round(v[0], 4) for k, v in prof.items() if v[1]},
         "psnr_y_db": round(psnr_ai, 4),
         "pcie_inclusive_fps": round(NFRAMES / pcie_dt, 1),
@@ -238,14 +458,9 @@ def main():
                         "pack_and_copy_ms": round(pack_dt * 1e3, 3), "upload_encode_pack_fps": round(NFRAMES / e2e_dt, 1),
                         "note": "5 kernels (count, 2 scans, zero, pack) + D2H of the bits only; pcie_inclusive_fps copies "
                                 "levels/flags/vectors/recon back instead"},
-        "decode": {"all_intra_fps": round(dec_ai_fps, 1), "ippp_fps": round(dec_ip_fps, 1),
+        "decode": {"all_intra_fps": round(dec_ai_fps, 1),
                    "note": "device reconstruction of the resident syntax of the same 300 frames (icsp_decode_resident), this rank"},
-        "ippp": {"workload": "stefanlike_cif 300f, --intraPeriod 10, QP=8 (BASELINE configs[2])", "value": round(fps2, 1),
-                 "unit": "frames/s", "ms_per_step": round(dt2 / steps2 * 1e3, 4), "psnr_y_db": round(psnr_ip, 4),
-                 "read_roofline_frac": round(fps2 / world * read_mean_ip / 1e9 / HBM_PEAK_GBS, 5),
-                 "kernels_ms_per_step": {k: round(v[0], 4) for k, v in prof2.items() if v[1]},
-                 "kernels_note": "event time summed over launches; the two GOP groups' P-step chains and the I-frame chroma "
-                                 "run on concurrent streams, so the sum exceeds ms_per_step"},
+        "ippp": ippp, "config4": config4, "config5": config5, "e2e": e2e,
     }
     print(json.dumps(line))
 

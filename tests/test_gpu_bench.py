@@ -33,15 +33,39 @@ def test_single_gpu_line():
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["psnr_y_db"] > 25 and d["ippp"]["value"] > 1e4
+    assert d["ranks_seen"] == 1 and all(d["parity"].values()) and len(d["parity"]) == 3
+    # the 8-GPU workloads of BASELINE configs[3] and [4], here on one GPU, outputs checked against the reference / the oracle
+    assert d["config4"]["frames"] == 3390 and d["config4"]["recon_equals_reference"] and d["config4"]["value"] > 1e4
+    assert d["config4"]["all_intra_loaded"]["value"] > 1e4
+    assert d["config5"]["frames"] == 3000 and d["config5"]["recon_equals_oracle"] and d["config5"]["value"] > 100
+    assert d["cpu_baseline"].get("single_thread") is None or d["cpu_baseline"]["single_thread"]["value"] > 0
+    assert d["e2e"]["rc"] == 0 and d["e2e"]["bin_equals_reference"] and d["e2e"]["recon_equals_reference"]
 
 
-def test_two_ranks_weak_scaling_path():
+def test_two_ranks_launched_the_drivers_way():
+    """torch.distributed.run starts the ranks (how the driver runs N > 1); both share the only GPU here."""
     env = dict(os.environ, ICSP_BENCH_BACKEND="gloo", ICSP_BENCH_FORCE_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+           "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--legs", "ippp"]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     d = _last_json(r.stdout)
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["scaling"] == "weak" and d["cpu_baseline"] is None
     # value is the aggregate over both ranks: 2 x 300 frames per step
     assert abs(d["value"] - 2 * 300 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+
+
+def test_gpus_flag_spawns_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts the two ranks and the
+    strong-scaling legs shard their GOPs over them (339 GOPs -> 170 + 169; 100 GOPs -> 50 + 50)."""
+    env = dict(os.environ, ICSP_BENCH_BACKEND="gloo", ICSP_BENCH_FORCE_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--legs", "config4,config5"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1200)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
+    assert d["config4"]["scaling"] == "strong" and d["config4"]["frames"] == 3390 and d["config4"]["recon_equals_reference"]
+    assert d["config5"]["scaling"] == "strong" and d["config5"]["frames"] == 3000 and d["config5"]["recon_equals_oracle"]
