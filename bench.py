@@ -392,8 +392,10 @@ def main():
             path = os.path.join(tmp, clipgen.file_name("foremanlike", NFRAMES))
             clip.tofile(path)
             t0 = time.perf_counter()
-            r = subprocess.run([enc_bin, "-i", path, "-n", str(NFRAMES), "-q", "16", "--intraPeriod", "0"], cwd=tmp, stdout=subprocess.PIPE,
-                               stderr=subprocess.STDOUT)
+            # relative input name: the output prefix is the input PATH up to its first '_' (encoder_main.cpp:10-17), and a
+            # temporary directory's name may contain one
+            r = subprocess.run([enc_bin, "-i", os.path.basename(path), "-n", str(NFRAMES), "-q", "16", "--intraPeriod", "0"], cwd=tmp,
+                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
             wall = time.perf_counter() - t0
             out = r.stdout.decode(errors="replace")
             e2e = {"wall_fps_incl_process_start_and_hip_init": round(NFRAMES / wall, 1), "rc": r.returncode}

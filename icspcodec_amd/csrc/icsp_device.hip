@@ -158,18 +158,6 @@ __device__ __forceinline__ int pad_fetch(const uint8_t* plane, int w, int h, int
     return zero ? 0 : v;
 }
 
-// Four consecutive pixels of the padded picture starting at padded column px0 (a multiple of 4; pad and w are too), as one
-// dword: inside the plane it is the plane's dword; in a side pad it is the row's first / last pixel replicated.
-__device__ __forceinline__ uint32_t pad_fetch_dw(const uint8_t* plane, int w, int h, int pad, int py, int px0)
-{
-    const int fy = min(max(py - pad, 0), h - 1), fx = px0 - pad;
-    const uint32_t dw = *(const uint32_t*)(plane + fy * w + min(max(fx, 0), w - 4));
-    uint32_t v = fx < 0 ? (dw & 0xffu) * 0x01010101u : (fx >= w ? (dw >> 24) * 0x01010101u : dw);
-    if (px0 + 3 == w + 2 * pad - 1) v &= 0x00ffffffu;           // the never-written last padded column (ENC:2239-2268)
-    if (py == h + 2 * pad - 1) v = 0;                           // and row
-    return v;
-}
-
 #include "icsp_me.hip.inc"
 
 // ------------------------------------------------------------------------------------------------ I-frame chroma DC chain
@@ -407,13 +395,13 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             // nobody waits inside that launch, see k_serial_fused); else two launches, the serial one with 1024 threads for
             // its staging loops
             const bool fused = g.nmb < 2048 && !ctx->no_fuse;
-            const int wpf4 = (g.nmb + 3) / 4, wpf16 = (g.nmb + 15) / 16;
+            const int tiles = ((g.sw + 1) / 2) * ((g.sh + 1) / 2);      // 2x2 macroblock tiles, one search workgroup each
             launch_timed(ctx, ICSP_K_ME, sk, [&] {
-                hipLaunchKernelGGL((k_me<false, 4>), dim3((unsigned)((long long)Gi * wpf4)), dim3(256), 0, sk, g, fs, b, wpf4);
-                if (!fused) hipLaunchKernelGGL((k_me<true, 16>), dim3((unsigned)((long long)Gi * wpf16)), dim3(1024), 0, sk, g, fs, b, wpf16);
+                hipLaunchKernelGGL((k_me<false>), dim3((unsigned)((long long)Gi * tiles)), dim3(256), 0, sk, g, fs, b, tiles);
+                if (!fused) hipLaunchKernelGGL((k_me<true>), dim3((unsigned)((long long)Gi * tiles)), dim3(256), 0, sk, g, fs, b, tiles);
             });
             launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
-                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3((unsigned)(Gi + (long long)Gi * wpf4)), dim3(256), serial_lds, sk, g, fs, b, Gi, wpf4);
+                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3((unsigned)(Gi + (long long)Gi * tiles)), dim3(256), serial_lds, sk, g, fs, b, Gi, tiles);
                 else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
             });
             launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, sk, g, fs, b, 0, 6, 1); });
