@@ -394,22 +394,40 @@ def main():
             t0 = time.perf_counter()
             # relative input name: the output prefix is the input PATH up to its first '_' (encoder_main.cpp:10-17), and a
             # temporary directory's name may contain one
-            r = subprocess.run([enc_bin, "-i", os.path.basename(path), "-n", str(NFRAMES), "-q", "16", "--intraPeriod", "0"], cwd=tmp,
+            r = subprocess.run([enc_bin, "-i", os.path.basename(path), "-n", str(NFRAMES), "-q", "16", "--intraPeriod", "0", "--stats"], cwd=tmp,
                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
             wall = time.perf_counter() - t0
             out = r.stdout.decode(errors="replace")
-            e2e = {"wall_fps_incl_process_start_and_hip_init": round(NFRAMES / wall, 1), "rc": r.returncode}
-            for line in out.splitlines():
-                if line.startswith("[icsp_enc]"):
-                    try:
-                        e2e.update(json.loads(line[len("[icsp_enc]"):]))
-                    except Exception:
-                        pass
+            e2e = {"workload": "icsp_enc: foremanlike 300 f file -> .bin + test_yuv.yuv (tmpfs), all-intra QP16", "rc": r.returncode,
+                   "wall_fps_incl_process_start_and_hip_init": round(NFRAMES / wall, 1)}
+
+            def stats(text):
+                for line in text.splitlines():
+                    if line.startswith("[icsp_enc]"):
+                        try:
+                            return json.loads(line[len("[icsp_enc]"):])
+                        except Exception:
+                            return None
+                return None
+            e2e["stats"] = stats(out)
             ref = next(s for s in golden if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", 300, 16, 0) and "bin_sha256" in s)
             binf = [f for f in os.listdir(tmp) if f.endswith(".bin")]
             e2e["bin_equals_reference"] = bool(binf) and hashlib.sha256(open(os.path.join(tmp, binf[0]), "rb").read()).hexdigest() == ref["bin_sha256"]
             ry = os.path.join(tmp, "test_yuv.yuv")
             e2e["recon_equals_reference"] = os.path.exists(ry) and hashlib.sha256(open(ry, "rb").read()).hexdigest() == ref["recon_sha256"]
+            # steady state: the same clip ten times over (3000 frames, 456 MB in, 456 MB + bits out), --intraPeriod 10
+            long_path = os.path.join(tmp, "long_cif(352X288)_3000f.yuv")
+            with open(long_path, "wb") as fh:
+                for _ in range(10):
+                    fh.write(clip.tobytes())
+            t0 = time.perf_counter()
+            r2 = subprocess.run([enc_bin, "-i", os.path.basename(long_path), "-n", "3000", "-q", "16", "--intraPeriod", "10", "--stats"], cwd=tmp,
+                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            wall2 = time.perf_counter() - t0
+            e2e["long_3000f_ippp"] = {"rc": r2.returncode, "wall_fps_incl_process_start_and_hip_init": round(3000 / wall2, 1),
+                                      "stats": stats(r2.stdout.decode(errors="replace"))}
+            os.remove(long_path)
+            os.remove(os.path.join(tmp, "long_compCIF_16_16_10.bin"))
 
     cpu = None if (a.no_cpu or world > 1 or rank != 0) else cpu_baseline()      # CPU baseline: rank 0 at N=1 only
     if world > 1:

@@ -91,36 +91,76 @@ static void write_header(const icsp_params_t* p, uint8_t* out)
     out[12] = (uint8_t)(outro & 0xff); out[13] = (uint8_t)(outro >> 8);
 }
 
+// One piece (an MSB-first bit string of `bits` bits, e.g. what icsp_pack_bits returned for one shard) into the body of a
+// .bin image at bit offset `at` (body = image + 14).  The image must have been zeroed (icsp_bitstream_begin).  Pieces cover
+// disjoint bit ranges, so different pieces may be placed by different threads at once: interior bytes are plain stores, the
+// first and last byte of a range (which a neighbour may share) are OR-ed in atomically.
+int icsp_bitstream_place(uint8_t* image, size_t cap, uint64_t at, const uint8_t* piece, uint64_t bits)
+{
+    if (!image || (!piece && bits)) return ICSP_ERR_UNENOUGH_PARAM;
+    if (bits == 0) return ICSP_OK;
+    if (cap < 14 + (size_t)((at + bits + 7) / 8)) return ICSP_ERR_RANGE;
+    uint8_t* dst = image + 14 + (size_t)(at >> 3);
+    const unsigned sh = (unsigned)(at & 7);
+    const size_t nsrc = (size_t)((bits + 7) / 8);                     // source bytes; padding bits of the last one are ignored
+    const size_t ndst = (size_t)((sh + bits + 7) / 8);                // destination bytes touched
+    auto src_at = [&](size_t j) -> unsigned {                         // byte j of the source with the padding bits cleared
+        if (j >= nsrc) return 0;
+        unsigned v = piece[j];
+        if (j == nsrc - 1 && (bits & 7)) v &= 0xff00u >> (bits & 7);
+        return v;
+    };
+    auto out_byte = [&](size_t j) -> uint8_t {                        // destination byte j of the shifted string
+        const unsigned hi = j ? src_at(j - 1) : 0, lo = src_at(j);
+        return (uint8_t)(((hi << 8 | lo) >> sh) & 0xff);
+    };
+    __atomic_fetch_or(&dst[0], out_byte(0), __ATOMIC_RELAXED);
+    if (ndst > 1) {
+        size_t j = 1;
+        if (sh == 0) { if (ndst > 2) memcpy(dst + 1, piece + 1, ndst - 2); j = ndst - 1; }
+        else for (; j + 1 < ndst && j + 1 < nsrc; j++) dst[j] = (uint8_t)((piece[j - 1] << (8 - sh)) | (piece[j] >> sh));
+        for (; j + 1 < ndst; j++) dst[j] = out_byte(j);              // (the source's last byte: padding bits masked)
+        __atomic_fetch_or(&dst[ndst - 1], out_byte(ndst - 1), __ATOMIC_RELAXED);
+    }
+    return ICSP_OK;
+}
+
+// Zeroes the image for a body of total_bits bits and writes the 14-byte header; *out_bytes = 14 + total_bits/8 + 1.
+int icsp_bitstream_begin(const icsp_params_t* p, uint64_t total_bits, uint8_t* image, size_t cap, size_t* out_bytes)
+{
+    if (!p || !image || !out_bytes) return ICSP_ERR_UNENOUGH_PARAM;
+    const size_t body = (size_t)(total_bits / 8) + 1;                  // fwrite(..., cntbits/8 + 1, ...) (ENC:4895, 5029)
+    if (cap < 14 + body + 1) return ICSP_ERR_RANGE;
+    memset(image, 0, 14 + body + 1);
+    write_header(p, image);
+    *out_bytes = 14 + body;
+    return ICSP_OK;
+}
+
+// After every piece is placed: the reference shifts bits into each byte from the right, so a final partial byte holds its
+// bits right-aligned (ENC:4956).
+int icsp_bitstream_end(uint8_t* image, uint64_t total_bits)
+{
+    if (!image) return ICSP_ERR_UNENOUGH_PARAM;
+    const unsigned r = (unsigned)(total_bits & 7);
+    uint8_t* dst = image + 14;
+    if (r) dst[total_bits >> 3] = (uint8_t)(dst[total_bits >> 3] >> (8 - r));
+    return ICSP_OK;
+}
+
 int icsp_bitstream_assemble(const icsp_params_t* p, int npieces, const uint8_t* const* pieces,
                             const uint64_t* piece_bits, uint8_t* out, size_t cap, size_t* out_bytes)
 {
     if (!p || !out || !out_bytes || npieces < 0 || (npieces > 0 && (!pieces || !piece_bits))) return ICSP_ERR_UNENOUGH_PARAM;
     uint64_t total = 0;
     for (int i = 0; i < npieces; i++) total += piece_bits[i];
-    const size_t body = (size_t)(total / 8) + 1;                       // fwrite(..., cntbits/8 + 1, ...) (ENC:4895, 5029)
-    if (cap < 14 + body + 1) return ICSP_ERR_RANGE;
-    memset(out, 0, 14 + body + 1);
-    write_header(p, out);
-    uint8_t* dst = out + 14;
-    uint64_t at = 0;                                                   // bits written so far
+    if (int rc = icsp_bitstream_begin(p, total, out, cap, out_bytes)) return rc;
+    uint64_t at = 0;
     for (int i = 0; i < npieces; i++) {
-        const uint8_t* src = pieces[i];
-        const size_t nb = (size_t)((piece_bits[i] + 7) / 8);
-        const unsigned sh = (unsigned)(at & 7);
-        uint8_t* d = dst + (at >> 3);
-        if (sh == 0) memcpy(d, src, nb);
-        else for (size_t j = 0; j < nb; j++) { d[j] |= (uint8_t)(src[j] >> sh); d[j + 1] |= (uint8_t)(src[j] << (8 - sh)); }
+        if (int rc = icsp_bitstream_place(out, cap, at, pieces[i], piece_bits[i])) return rc;
         at += piece_bits[i];
-        // drop the padding bits of this piece's last byte so the next piece can be OR-ed in
-        const unsigned keep = (unsigned)(at & 7);
-        dst[at >> 3] &= (uint8_t)(keep ? (0xff00u >> keep) : 0);
-        dst[(at >> 3) + 1] = 0;
     }
-    // the reference shifts bits into each byte from the right, so a final partial byte holds its bits right-aligned
-    const unsigned r = (unsigned)(total & 7);
-    if (r) dst[total >> 3] = (uint8_t)(dst[total >> 3] >> (8 - r));
-    *out_bytes = 14 + body;
-    return ICSP_OK;
+    return icsp_bitstream_end(out, total);
 }
 
 // ---- the inverse: readHeader (DEC:14-37) and readBlockData (DEC:38-405) of the reference DECODER

@@ -91,6 +91,19 @@ __device__ unsigned long long g_diag[16];
 #define DIAG_BEGIN
 #endif
 
+#ifdef ICSP_TIMELINE
+// Diagnostic build only (tools/timeline.hip): every workgroup of the P-step kernels logs (start, end) in 100 MHz
+// s_memrealtime ticks into a slot of its own (kernel, GOP group, block): no atomics, so the logging does not serialise the
+// workgroups; a later launch of the same kernel overwrites an earlier one, what is read back is the LAST P step of a pass.
+struct TlEntry { unsigned long long t0, t1; };
+__device__ TlEntry g_tl[8 * 2 * 8192];
+#define TL_BEGIN const unsigned long long tl_t0 = __builtin_amdgcn_s_memrealtime();
+#define TL_END(id, grp) if (threadIdx.x == 0 && blockIdx.x < 8192) { TlEntry* e_ = &g_tl[((id) * 2 + (grp)) * 8192 + blockIdx.x]; e_->t0 = tl_t0; e_->t1 = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define TL_BEGIN
+#define TL_END(id, grp)
+#endif
+
 // ------------------------------------------------------------------------------------------------ geometry
 struct Geo {
     int W, H, sw, sh, nmb, cols8, rows8, cw, ch;
@@ -222,7 +235,8 @@ struct icsp_ctx {
     bool s2_dirty, st_ahead, always_sync;
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
     int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
-    int p_groups;                     // GOP groups whose P-step chains run on separate streams
+    int p_groups, prio_hi;            // GOP groups whose P-step chains run on separate streams (created on first use: a stream costs
+                                      // milliseconds to create, and an all-intra encode never needs them)
     hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
     hipEvent_t ev_pjoin[kMaxPGroups];
     DevBufs b;
@@ -376,6 +390,11 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     if (NG > G / 4) NG = G / 4;                        // keep every group's launches wide enough to be worth splitting
     if (NG < 1) NG = 1;
     if (L > 1 && NG > 1) {
+        for (int k = 1; k < NG; k++)
+            if (!ctx->pstream[k]) {
+                HIPCHK(hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, ctx->prio_hi));
+                HIPCHK(hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming));
+            }
         hipEventRecord(ctx->ev_fork, st);
         for (int k = 1; k < NG; k++) hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0);
     }
@@ -511,6 +530,14 @@ int icsp_device_count(void)
     return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? n : 0;
 }
 
+void* icsp_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    return (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess) ? p : nullptr;
+}
+
+void icsp_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 const char* icsp_kernel_name(int k)
 {
     static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode" };
@@ -569,10 +596,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipFuncSetAttribute((const void*)k_dec_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
-    for (int k = 1; k < ctx->p_groups; k++) {
-        if ((e = hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, prio_hi)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
-        if ((e = hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
-    }
+    ctx->prio_hi = prio_hi;            // the streams of the additional GOP groups are created by the first P step that uses them
     // k_frame_serial stages a frame's block sums, vectors and states in dynamic LDS: 15 bytes per macroblock
     if ((e = hipFuncSetAttribute((const void*)k_frame_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);

@@ -133,6 +133,19 @@ int icsp_pack_bits(icsp_ctx_t* ctx, int first_frame, int n, uint8_t* body, size_
 int icsp_bitstream_assemble(const icsp_params_t* params, int npieces, const uint8_t* const* pieces,
                             const uint64_t* piece_bits, uint8_t* out, size_t cap, size_t* out_bytes);
 
+/* The same in steps, for hosts that place the pieces of several shards from several threads (icsp_enc): begin zeroes the image
+ * and writes the header, place puts one piece at its bit offset in the body (thread-safe for disjoint bit ranges), end
+ * right-aligns the final partial byte. */
+int icsp_bitstream_begin(const icsp_params_t* params, uint64_t total_bits, uint8_t* image, size_t cap, size_t* out_bytes);
+int icsp_bitstream_place(uint8_t* image, size_t cap, uint64_t bit_offset, const uint8_t* piece, uint64_t piece_bits);
+int icsp_bitstream_end(uint8_t* image, uint64_t total_bits);
+
+/* ---- pinned host memory for the transfers (hipHostMalloc): uploads and downloads from/to it run at PCIe speed and
+ *      overlap with kernels of other contexts; any host pointer works with every call, pageable ones are staged by the
+ *      runtime.  NULL when there is no device or no memory. ---- */
+void* icsp_host_alloc(size_t bytes);
+void icsp_host_free(void* p);
+
 /* ---- decoder side: DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp ---- */
 /* Host: readHeader (DEC:14-37).  intra_period is the header field as stored: 1 (or 0) = every frame intra (DEC.h:293). */
 int icsp_parse_header(const uint8_t* bin, size_t nbytes, icsp_params_t* out);
