@@ -235,6 +235,7 @@ struct icsp_ctx {
     bool s2_dirty, st_ahead, always_sync;
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
     int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
+    int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
     int p_groups, prio_hi;            // GOP groups whose P-step chains run on separate streams (created on first use: a stream costs
                                       // milliseconds to create, and an all-intra encode never needs them)
     hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
@@ -487,13 +488,35 @@ int decode_range(icsp_ctx* ctx, int first, int n)
     return 0;
 }
 
+template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
+{
+    hipLaunchKernelGGL((k_intra_luma8<NW>), dim3(G), dim3(NW * 64), 0, st, g, fs, b);
+}
+
 void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
     // 32-lane form: two blocks per wave.  `need` waves cover the widest wavefront step in one round.
     // With at most one I frame per CU the kernel is pure latency: use `need` waves.  With more frames than CUs, cap at 8
     // waves x 128 VGPRs so two workgroups share a CU and every frame of the batch is in flight at once (measured on
     // 300 CIF frames: 0.45 ms vs 0.57 ms).
+    // 8-lane form (eight blocks per wave, k_intra_luma8): fewer instructions per block, more per wave and step.  It wins
+    // when the CUs are loaded anyway (more than two frames per CU) and on frames too wide for one round of the 32-lane form.
     const int need = ctx->intra_waves;
+    const int need8 = (need * 2 + 7) / 8;                           // waves of eight blocks for the widest step
+    int form = ctx->force_intra_form;
+    if (!form) form = (G > 2 * ctx->n_cu || need > 16) ? 8 : 32;
+    if (form == 8) {
+        const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : need8;
+        if (nw <= 1)       launch_intra8<1>(g, fs, b, G, st);
+        else if (nw <= 2)  launch_intra8<2>(g, fs, b, G, st);
+        else if (nw <= 3)  launch_intra8<3>(g, fs, b, G, st);
+        else if (nw <= 4)  launch_intra8<4>(g, fs, b, G, st);
+        else if (nw <= 6)  launch_intra8<6>(g, fs, b, G, st);
+        else if (nw <= 8)  launch_intra8<8>(g, fs, b, G, st);
+        else if (nw <= 12) launch_intra8<12>(g, fs, b, G, st);
+        else               launch_intra8<16>(g, fs, b, G, st);
+        return;
+    }
     const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : (G > ctx->n_cu ? (need < 8 ? need : 8) : need);
     if (nw <= 2)       hipLaunchKernelGGL((k_intra_luma32<2, 1>), dim3(G), dim3(128), 0, st, g, fs, b);
     else if (nw <= 4)  hipLaunchKernelGGL((k_intra_luma32<4, 1>), dim3(G), dim3(256), 0, st, g, fs, b);
@@ -578,11 +601,12 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
     int no_fuse = 0;
-    ctx->force_intra_nw = 0;
+    ctx->force_intra_nw = 0; ctx->force_intra_form = 0;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured: 2 groups +7 %, 3 no better, more streams than hardware queues collapse
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) ||
-        !env_int("ICSP_INTRA_NW", 2, 16, &ctx->force_intra_nw)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
+        !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
+        (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     ctx->no_fuse = no_fuse != 0;
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
     auto fail = [&](int code, const char* what, hipError_t e) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); icsp_destroy(ctx); return code; };

@@ -1,0 +1,84 @@
+"""The throughput form of the intra luma kernel (k_intra_luma8: eight lanes per block, eight blocks per wave) against the
+oracle, forced through ICSP_INTRA_FORM=8 on batches where the default would pick the 32-lane latency form, and the default
+choice on a batch large enough to pick it by itself.  Same reference code as the 32-lane form: DPCM_pix_block ENC:851-1499,
+DCT_block ENC:2685, DPCM_DC_block ENC:3643, Quantization_block ENC:2750, IDCT_block ENC:2825, IDPCM_pix_block ENC:1500-1875
+(ENC = /root/reference/source/encoder/ICSP_Codec_Encoder_source.cpp)."""
+import os
+
+import numpy as np
+import pytest
+
+from icspcodec_amd import capi, clipgen
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+KEYS = ("levels", "acflag", "mpm", "mvd", "recon")
+NT = min(os.cpu_count() or 1, 64)
+
+
+def _cmp(got, want, ctx=""):
+    for k in KEYS:
+        if not np.array_equal(got[k], want[k]):
+            bad = np.argwhere(got[k] != want[k])
+            raise AssertionError(f"{ctx}{k}: {len(bad)} mismatches, first at {bad[0].tolist()}: "
+                                 f"got {got[k][tuple(bad[0])]} want {want[k][tuple(bad[0])]}")
+
+
+@pytest.fixture
+def form8():
+    os.environ["ICSP_INTRA_FORM"] = "8"
+    yield
+    del os.environ["ICSP_INTRA_FORM"]
+
+
+@pytest.mark.parametrize("name,n,qdc,qac,period,w,h", [
+    ("foremanlike", 4, 16, 16, 0, 352, 288), ("mobilelike", 3, 1, 1, 0, 352, 288), ("stefanlike", 6, 8, 8, 3, 352, 288),
+    ("mobilelike", 3, 16, 1, 3, 352, 288), ("staticlike", 4, 1, 1, 4, 352, 288), ("tablelike", 3, 8, 8, 0, 64, 48),
+    ("newslike", 2, 16, 16, 0, 32, 16), ("stefanlike", 3, 8, 8, 3, 416, 240), ("mobilelike", 2, 8, 8, 0, 704, 576),
+    ("tablelike", 3, 16, 16, 3, 1920, 1088), ("mobilelike", 2, 16, 16, 2, 2048, 1088),
+])
+def test_forced_8_lane_form_matches_oracle(form8, name, n, qdc, qac, period, w, h):
+    clip = clipgen.synth_clip(name, n, width=w, height=h)
+    enc = capi.Encoder(w, h, qdc, qac, period, max_frames=n)
+    enc.keep_coef(True)
+    got = enc.encode(clip)
+    coef = enc.download_coef(0, 1)
+    mv, mode = enc.download_debug(0, n)
+    enc.close()
+    want = po.encode_sequence(clip, w, h, qdc, qac, period, nthreads=NT)
+    _cmp(got, want, f"{name} {w}x{h} n={n} q={qdc}/{qac} p={period}: ")
+    dbg = po.intra_frame(clip[0], w, h, qdc, qac, want_dbg=True)
+    assert np.array_equal(coef[0].view(np.int64), dbg["coef"].view(np.int64))        # forward DCT coefficients: 0 ulp
+    assert np.array_equal(mode[0], dbg["mode"])
+
+
+@pytest.mark.parametrize("nw", ["1", "2", "16"])
+def test_8_lane_form_any_workgroup_width(form8, nw):
+    """Fewer waves than the widest step needs (several rounds per step) and more than it needs (idle waves)."""
+    os.environ["ICSP_INTRA_NW"] = nw
+    try:
+        clip = clipgen.synth_clip("foremanlike", 2)
+        enc = capi.Encoder(352, 288, 16, 16, 0, max_frames=2)
+        got = enc.encode(clip)
+        enc.close()
+    finally:
+        del os.environ["ICSP_INTRA_NW"]
+    _cmp(got, po.encode_sequence(clip, 352, 288, 16, 16, 0), f"NW={nw}: ")
+
+
+def test_default_picks_the_8_lane_form_on_a_loaded_chip():
+    """More than two frames per CU: 600 all-intra CIF frames (the reference clip twice) -> the 300-frame reference hash twice."""
+    import hashlib
+    import json
+    clip = clipgen.synth_clip("foremanlike", 300)
+    enc = capi.Encoder(352, 288, 16, 16, 0, max_frames=600)
+    enc.upload(np.concatenate([clip, clip]))
+    enc.encode_resident(0, 600)
+    rec = enc.download(0, 600, what=("recon",))["recon"]
+    bs = enc.pack_bitstream(0, 300)
+    enc.close()
+    ref = next(s for s in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "streams.json")))
+               if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", 300, 16, 0) and "bin_sha256" in s)
+    assert hashlib.sha256(rec[:300].tobytes()).hexdigest() == ref["recon_sha256"]
+    assert hashlib.sha256(rec[300:].tobytes()).hexdigest() == ref["recon_sha256"]
+    assert hashlib.sha256(bs).hexdigest() == ref["bin_sha256"]
