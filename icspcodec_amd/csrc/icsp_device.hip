@@ -171,6 +171,38 @@ __device__ __forceinline__ int pad_fetch(const uint8_t* plane, int w, int h, int
     return zero ? 0 : v;
 }
 
+// XCD-aware placement of a launch's workgroups.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share
+// one: observed on gfx950, used for speed only, never for correctness), and every XCD has an L2 of its own.  A frame's
+// workgroups read overlapping lines (search windows, prediction rows) and the next kernel of the P step reads what this
+// one wrote, so all workgroups of frame f of a launch -- in every kernel of the step -- get block indices congruent to
+// f mod 8: the frame's lines are fetched into ONE L2 instead of up to eight (k_me moved 5.7x its algorithmic bytes with a
+// linear mapping).  Block b -> (frame, unit within the frame); grids are padded to 8 * ceil(frames / 8) frames, blocks of
+// the padding frames return at once.
+// When a launch has few frames (or they are large) a frame is cut into `slices` runs of consecutive units (bands of the
+// frame) and the (frame, slice) pairs are dealt over the XCDs instead, so that all 8 XCDs have work.
+struct XcdUnit { int frame, unit; };          // unit >= per_frame or frame >= frames: padding, the workgroup returns at once
+__device__ __forceinline__ XcdUnit xcd_unit(int b, int per_frame, int slices)
+{
+    const int per_vf = (per_frame + slices - 1) / slices;           // everything here is wave-uniform: scalar arithmetic
+    const int x = b & 7, j = b >> 3, q = j / per_vf;
+    const int vf = x + 8 * q, frame = vf / slices, slice = vf - frame * slices;
+    const int unit = slice * per_vf + (j - q * per_vf);
+    return XcdUnit{ unit < per_frame ? frame : 0x7fffffff, unit };
+}
+int g_force_slices = 0;                                             // ICSP_XCD_SLICES (experiments); 0 = automatic
+inline int xcd_slices(int frames, int per_frame)
+{
+    if (g_force_slices > 0) return g_force_slices <= per_frame ? g_force_slices : per_frame;
+    int s = 1;                                                      // a power of two up to 8: frames * s pairs deal out evenly ...
+    while (s < 8 && frames * s < 32 && per_frame / (2 * s) >= 32) s *= 2;       // ... in slices of at least 32 units
+    return s;
+}
+inline unsigned xcd_grid(int frames, int per_frame, int slices)
+{
+    const int per_vf = (per_frame + slices - 1) / slices;
+    return 8u * (unsigned)((frames * slices + 7) / 8) * (unsigned)per_vf;
+}
+
 #include "icsp_me.hip.inc"
 
 // ------------------------------------------------------------------------------------------------ I-frame chroma DC chain
@@ -376,9 +408,10 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             ctx->st_ahead = false;
         }
         launch_timed(ctx, ICSP_K_INTRA_LUMA, st, [&] { launch_intra_luma(ctx, g, fs, b, G, st); });
-        const long long nblk = (long long)G * g.nmb * 2;
+        const int cwgs = (int)((g.nmb * 2 + 31) / 32);                // k_residual8 workgroups (32 blocks) per frame, chroma only
         launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
-        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s2, g, fs, b, 4, 2, 0); });
+        const int sc_ = xcd_slices(G, cwgs);
+        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(G, cwgs, sc_)), dim3(256), 0, s2, g, fs, b, 4, 2, 0, cwgs, sc_); });
         ctx->s2_dirty = true;
         if (!lazy) join_s2(ctx);
     }
@@ -416,15 +449,18 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             // its staging loops
             const bool fused = g.nmb < 2048 && !ctx->no_fuse;
             const int tiles = ((g.sw + 1) / 2) * ((g.sh + 1) / 2);      // 2x2 macroblock tiles, one search workgroup each
+            const int res_wgs = (int)((g.nmb * 6 + 31) / 32);            // k_residual8 workgroups (32 blocks) per frame
+            const unsigned n_serial8 = 8u * (unsigned)((Gi + 7) / 8);
+            const int st_ = xcd_slices(Gi, tiles), sr_ = xcd_slices(Gi, res_wgs);
             launch_timed(ctx, ICSP_K_ME, sk, [&] {
-                hipLaunchKernelGGL((k_me<false>), dim3((unsigned)((long long)Gi * tiles)), dim3(256), 0, sk, g, fs, b, tiles);
-                if (!fused) hipLaunchKernelGGL((k_me<true>), dim3((unsigned)((long long)Gi * tiles)), dim3(256), 0, sk, g, fs, b, tiles);
+                hipLaunchKernelGGL((k_me<false>), dim3(xcd_grid(Gi, tiles, st_)), dim3(256), 0, sk, g, fs, b, tiles, st_);
+                if (!fused) hipLaunchKernelGGL((k_me<true>), dim3(xcd_grid(Gi, tiles, st_)), dim3(256), 0, sk, g, fs, b, tiles, st_);
             });
             launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
-                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3((unsigned)(Gi + (long long)Gi * tiles)), dim3(256), serial_lds, sk, g, fs, b, Gi, tiles);
+                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, tiles, st_)), dim3(256), serial_lds, sk, g, fs, b, (int)n_serial8, tiles, st_);
                 else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
             });
-            launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, sk, g, fs, b, 0, 6, 1); });
+            launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(Gi, res_wgs, sr_)), dim3(256), 0, sk, g, fs, b, 0, 6, 1, res_wgs, sr_); });
         }
         if (!any) break;
     }
@@ -606,7 +642,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->p_groups = 2;                 // measured: 2 groups +7 %, 3 no better, more streams than hardware queues collapse
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) ||
         !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
-        (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
+        (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32) ||
+        !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     ctx->no_fuse = no_fuse != 0;
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
     auto fail = [&](int code, const char* what, hipError_t e) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); icsp_destroy(ctx); return code; };

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round profile on the GPU box (run from the repo root through gpurun): kernel-trace stats of the bench command, then PMC
+# passes (counters in runs of their own, the program directly after `--`), then the traffic calibration.  Output under
+# gpurun_out/$1/ ; tools/summarize_profiles.py condenses it into profiles/.
+set -u
+TAG=${1:-r02}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --legs ippp > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+W="python3 $R/tools/pmc_workload.py"
+rocprofv3 --pmc FETCH_SIZE SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d $OUT/pmc_a --output-format csv -- $W > /dev/null 2> $OUT/pmc_a.err
+rocprofv3 --pmc WRITE_SIZE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_CVT SQ_INSTS_LDS SQ_ACTIVE_INST_LDS -d $OUT/pmc_b --output-format csv -- $W > /dev/null 2> $OUT/pmc_b.err
+rocprofv3 --pmc TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B -d $OUT/pmc_c --output-format csv -- $W > /dev/null 2> $OUT/pmc_c.err
+rocprofv3 --pmc TCC_EA0_WRREQ TCC_EA0_WRREQ_64B TCC_HIT TCC_MISS -d $OUT/pmc_d --output-format csv -- $W > /dev/null 2> $OUT/pmc_d.err
+for p in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ TCC_EA0_RDREQ_32B TCC_EA0_RDREQ_64B TCC_EA0_RDREQ_128B" "TCC_EA0_WRREQ TCC_EA0_WRREQ_64B"; do
+  n=$(echo $p | tr ' ' '_' | cut -c1-24)
+  rocprofv3 --pmc $p -d $OUT/cal_$n --output-format csv -- $R/tools/calib_traffic.bin > $OUT/cal_$n.out 2> $OUT/cal_$n.err
+done
+cd $R
+python3 tools/summarize_profiles.py $OUT $TAG > $OUT/summary.txt 2>&1
+tail -30 $OUT/summary.txt
+# keep what is merged back small: the condensed files only
+rm -rf $OUT/stats/*/*_agent_info.csv
+find $OUT -name "*.csv" -size +8M -delete

@@ -1,51 +1,153 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 outputs merged under gpurun_out/ into the tracked summaries under profiles/.
+"""Condense the rocprofv3 outputs of tools/profile_round.sh (merged under gpurun_out/<tag>/) into the tracked summaries
+under profiles/:
 
-    python tools/summarize_profiles.py <stats_dir> <pmc_fetch_dir> <pmc_write_dir> <bench_json> <tag>
+    python tools/summarize_profiles.py gpurun_out/<tag> <tag>
 
-Traffic: bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch, the gfx950 correction of MI355X_MICROARCH.md §HBM (FETCH_SIZE
-reports half the bytes of a coalesced read; confirmed here on __amd_rocclr_copyBuffer)."""
-import collections, csv, glob, json, os, shutil, sys
+  profiles/<tag>_kernel_stats_bench.csv   rocprofv3 --kernel-trace --stats of the bench command (per-kernel calls / average ns)
+  profiles/<tag>_bench_profiled.json      the bench line printed under the profiler
+  profiles/traffic.json                   per kernel launch: HBM-side bytes from the TCC counters, the calibration of those
+                                          counters on known byte counts, SQ instruction / cycle counters, derived fractions
 
-stats_dir, fdir, wdir, bench_json, tag = sys.argv[1:6]
+Traffic: rocprofv3's FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes
+(MI355X_MICROARCH.md, HBM), i.e. reports half the bytes of a wide coalesced read; the calibration run (tools/calib_traffic.hip,
+512 MiB moved once by 2-, 4-, 8-, 16-byte-per-lane accesses and by the codec's 8-byte block rows) gives the factor for each
+access width, and the request-size counters TCC_EA0_RDREQ_{32B,64B,128B} give the bytes without any factor:
+    read bytes  = 32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B        (checked against the known byte counts below)
+    write bytes = WRITE_SIZE * 1024
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+out_dir, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P, NMB = 352 * 288, 396
+KERNELS = ("k_dec_intra_luma32", "k_dec_serial", "k_dec_blocks", "k_intra_luma32", "k_intra_luma8", "k_chroma_dc", "k_residual8", "k_me<false",
+           "k_me<true", "k_serial_fused", "k_frame_serial", "k_bits_count", "k_bits_scan", "k_chunk_base", "k_pack_zero", "k_pack",
+           "cal_read_rows8", "cal_read", "cal_write")
+
 
 def short(n):
-    for k in ("k_dec_intra_luma32", "k_dec_serial", "k_dec_blocks", "k_intra_luma32", "k_chroma_dc", "k_residual8", "k_me<false",
-              "k_me<true", "k_serial_fused", "k_frame_serial", "k_bits_count", "k_bits_scan", "k_chunk_base", "k_pack_zero", "k_pack"):
+    for k in KERNELS:
         if k in n:
-            return k.replace("<", "_").rstrip("_")
+            s = k.replace("<", "_").rstrip("_")
+            if s in ("cal_read", "cal_write"):
+                for t, b in (("unsigned int, 2", 8), ("unsigned int, 4", 16), ("unsigned short", 2), ("unsigned int", 4)):
+                    if t in n:
+                        s += f"_{b}B"
+                        break
+            return s
     return n.split("(")[0][-40:]
 
-shutil.copy(glob.glob(os.path.join(stats_dir, "*", "*kernel_stats.csv"))[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_bench.csv"))
-shutil.copy(bench_json, os.path.join(ROOT, "profiles", f"{tag}_bench.json"))
-rows = collections.defaultdict(dict)
-copy_cal = {}
-for name, d in (("FETCH_SIZE", fdir), ("WRITE_SIZE", wdir)):
-    agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0])):
-        if r["Counter_Name"] != name:
-            continue
-        if "copyBuffer" in r["Kernel_Name"] and r["Grid_Size"] == "65536":
-            copy_cal.setdefault(name, []).append(float(r["Counter_Value"]))
-        if "rocclr" in r["Kernel_Name"]:
-            continue
-        agg[(short(r["Kernel_Name"]), int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
-    for k, v in agg.items():
-        rows[k][name] = sum(v) / len(v)
-        rows[k]["launches"] = len(v)
-alg = {"k_intra_luma32": lambda frames: frames * (4 * P + 8 * NMB)}
-out = {"method": __doc__.split("Traffic:")[1].strip(), "unit_of_counters": "KB",
-       "copy_calibration_1MiB": {k: sum(v) / len(v) for k, v in copy_cal.items()}, "kernels": {}}
-for (kn, grid), d in sorted(rows.items()):
-    f, w = d.get("FETCH_SIZE", 0.0), d.get("WRITE_SIZE", 0.0)
-    e = {"grid_threads": grid, "launches_seen": d["launches"], "FETCH_SIZE_KB": round(f, 1), "WRITE_SIZE_KB": round(w, 1),
-         "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
-    out["kernels"][f"{kn}@{grid}"] = e
-# the bench's dominant kernel: the 300-frame all-intra launch of k_intra_luma32 (largest grid)
-big = max((k for k in out["kernels"] if k.startswith("k_intra_luma32")), key=lambda k: out["kernels"][k]["grid_threads"])
-out["k_intra_luma_bytes_per_launch"] = out["kernels"][big]["hbm_bytes_per_launch"]
-out["k_intra_luma_algorithmic_bytes_per_launch"] = 300 * (4 * P + 8 * NMB)
+
+def counters(sub):
+    """{(kernel, grid): {counter: mean value over dispatches}} of one PMC pass directory."""
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "rocclr" in r["Kernel_Name"]:
+                continue
+            agg[(short(r["Kernel_Name"]), int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: {c: sum(v) / len(v) for c, v in d.items()} | {"_launches": max(len(v) for v in d.values())} for k, d in agg.items()}
+
+
+os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+stats = glob.glob(os.path.join(out_dir, "stats", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_bench.csv"))
+bj = os.path.join(out_dir, "bench_profiled.json")
+if os.path.exists(bj) and os.path.getsize(bj):
+    shutil.copy(bj, os.path.join(ROOT, "profiles", f"{tag}_bench_profiled.json"))
+
+# ---- calibration on known byte counts
+cal = {}
+KNOWN = 512 * 1024 * 1024
+for sub in sorted(glob.glob(os.path.join(out_dir, "cal_*"))):
+    if not os.path.isdir(sub):
+        continue
+    for (kn, grid), d in counters(os.path.basename(sub)).items():
+        e = cal.setdefault(kn, {"known_bytes": 5000 * P if "rows8" in kn else KNOWN})
+        for c, v in d.items():
+            if not c.startswith("_"):
+                e[c] = v
+for kn, e in cal.items():
+    kb = e["known_bytes"]
+    if "FETCH_SIZE" in e and "read" in kn:
+        e["bytes_per_FETCH_SIZE_KiB_unit"] = round(kb / e["FETCH_SIZE"], 1)          # 1024 would be exact; 2048 = "reports half"
+    if "WRITE_SIZE" in e and "write" in kn:
+        e["bytes_per_WRITE_SIZE_KiB_unit"] = round(kb / e["WRITE_SIZE"], 1)
+    if "TCC_EA0_RDREQ_32B" in e and "read" in kn:
+        rd = 32 * e.get("TCC_EA0_RDREQ_32B", 0) + 64 * e.get("TCC_EA0_RDREQ_64B", 0) + 128 * e.get("TCC_EA0_RDREQ_128B", 0)
+        e["rdreq_sized_bytes_over_known"] = round(rd / kb, 4)
+    if "TCC_EA0_WRREQ" in e and "write" in kn:
+        e["wrreq_x64_over_known"] = round(64 * e["TCC_EA0_WRREQ"] / kb, 4)
+
+# ---- the codec's kernels
+a, b, c, d = counters("pmc_a"), counters("pmc_b"), counters("pmc_c"), counters("pmc_d")
+keys = sorted(set(a) | set(b) | set(c) | set(d))
+# read factor for FETCH_SIZE in the codec's access shape (8-byte block rows), from the calibration; 2048 if it was not run
+f_rows = cal.get("cal_read_rows8", {}).get("bytes_per_FETCH_SIZE_KiB_unit", 2048.0)
+kernels = {}
+for k in keys:
+    kn, grid = k
+    e = {"grid_threads": grid, "launches_seen": int(max(x.get(k, {}).get("_launches", 0) for x in (a, b, c, d)))}
+    for src in (a, b, c, d):
+        for cn, v in src.get(k, {}).items():
+            if not cn.startswith("_"):
+                e[cn] = round(v, 1)
+    if "TCC_EA0_RDREQ_32B" in e:
+        e["read_bytes_per_launch"] = int(32 * e.get("TCC_EA0_RDREQ_32B", 0) + 64 * e.get("TCC_EA0_RDREQ_64B", 0) + 128 * e.get("TCC_EA0_RDREQ_128B", 0))
+    elif "FETCH_SIZE" in e:
+        e["read_bytes_per_launch"] = int(e["FETCH_SIZE"] * f_rows)
+    if "WRITE_SIZE" in e:
+        e["write_bytes_per_launch"] = int(e["WRITE_SIZE"] * 1024)
+    if "read_bytes_per_launch" in e and "write_bytes_per_launch" in e:
+        e["hbm_bytes_per_launch"] = e["read_bytes_per_launch"] + e["write_bytes_per_launch"]
+    f64 = e.get("SQ_INSTS_VALU_ADD_F64", 0) + e.get("SQ_INSTS_VALU_MUL_F64", 0) + e.get("SQ_INSTS_VALU_FMA_F64", 0)
+    if "SQ_INSTS_VALU" in e:
+        e["fp64_valu_insts_per_launch"] = int(f64)
+        e["fp64_share_of_valu_insts"] = round(f64 / max(e["SQ_INSTS_VALU"], 1), 4)
+    if "SQ_WAVE_CYCLES" in e and "SQ_WAIT_INST_ANY" in e:
+        e["issue_stall_share_of_wave_cycles"] = round(e["SQ_WAIT_INST_ANY"] / max(e["SQ_WAVE_CYCLES"], 1), 4)
+        e["waiting_share_of_wave_cycles"] = round(e.get("SQ_WAIT_ANY", 0) / max(e["SQ_WAVE_CYCLES"], 1), 4)
+        e["valu_active_share_of_wave_cycles"] = round(e.get("SQ_ACTIVE_INST_VALU", 0) / max(e["SQ_WAVE_CYCLES"], 1), 4)
+    kernels[f"{kn}@{grid}"] = e
+
+# algorithmic bytes of the launches the bench line and VERDICT quote (300 CIF frames; 15 frames per P-step launch)
+ALG = {"k_intra_luma32": lambda fr: fr * (4 * P + 8 * NMB), "k_me_false": lambda fr: fr * (3 * P + 64 * NMB),
+       "k_residual8": lambda fr: fr * (3 * P + P * 3 // 2 + 3 * P + 8 * NMB)}
+for name, e in kernels.items():
+    kn, grid = name.split("@")
+    grid = int(grid)
+    frames = None
+    if kn == "k_intra_luma32":
+        frames = grid // 512 if grid >= 512 * 256 else grid // 704          # <8,4> above 256 frames, else <11,1>
+    elif kn == "k_me_false":
+        frames = 15                                                          # configs[2]: 30 GOPs in two groups (the grid is padded to 16 frames)
+    elif kn == "k_residual8" and 900 < grid // 256 < 1400:
+        frames = 15                                                          # P-step launch of configs[2]
+    if frames and kn in ALG and "hbm_bytes_per_launch" in e:
+        e["frames_per_launch"] = frames
+        e["algorithmic_bytes_per_launch"] = ALG[kn](frames)
+        e["traffic_over_algorithmic"] = round(e["hbm_bytes_per_launch"] / e["algorithmic_bytes_per_launch"], 3)
+
+out = {"method": __doc__.split("Traffic:")[1].strip(), "calibration": cal, "kernels": kernels}
+big = [k for k in kernels if k.startswith("k_intra_luma32@") and "hbm_bytes_per_launch" in kernels[k]]
+if big:
+    bk = max(big, key=lambda k: kernels[k]["grid_threads"])
+    out["k_intra_luma_bytes_per_launch"] = kernels[bk]["hbm_bytes_per_launch"]
+    out["k_intra_luma_algorithmic_bytes_per_launch"] = 300 * (4 * P + 8 * NMB)
+    out["k_intra_luma_sq"] = {"fp64_valu_insts_per_launch": kernels[bk].get("fp64_valu_insts_per_launch"),
+                              "valu_insts_per_launch": kernels[bk].get("SQ_INSTS_VALU"),
+                              "issue_stall_share_of_wave_cycles": kernels[bk].get("issue_stall_share_of_wave_cycles"),
+                              "source": f"rocprofv3 --pmc SQ_INSTS_VALU_{{ADD,MUL,FMA}}_F64 on {bk} (profiles/traffic.json, tools/profile_round.sh)"}
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
-print(big, out["kernels"][big], out["copy_calibration_1MiB"])
+print(json.dumps({"calibration": cal}, indent=1))
+for k, e in kernels.items():
+    print(k, {x: e[x] for x in ("launches_seen", "read_bytes_per_launch", "write_bytes_per_launch", "traffic_over_algorithmic", "fp64_share_of_valu_insts",
+                                "issue_stall_share_of_wave_cycles", "valu_active_share_of_wave_cycles") if x in e})
