@@ -16,8 +16,8 @@ int main()
     for (int rep = 0; rep < 5; rep++) { icsp_encode_resident(ctx, 0, nframes); icsp_sync(ctx); }
     unsigned long long d[16];
     hipMemcpyFromSymbol(d, HIP_SYMBOL(g_diag), sizeof(d));
-    const char* names[3] = {"tables + window loads -> LDS + barrier", "SAD loop (64 candidates)", "resolve + block sums + stores"};
-    for (int i = 0; i < 3; i++) printf("%-42s %8llu cyc  %6.2f us\n", names[i], d[i], d[i] / 2400.0);
+    const char* names[5] = {"LDS writes + barrier", "SAD loop (64 candidates)", "resolve + block sums + stores", "entry -> kernel args + tables in registers", "issue + wait: current rows, window segments"};
+    for (int i : {3, 4, 0, 1, 2}) printf("%-46s %8llu cyc  %6.2f us\n", names[i], d[i], d[i] / 2400.0);
     printf("wave 0 of workgroup 0: %llu shader cycles, %llu x10ns realtime\n", d[9], d[8]);
     icsp_destroy(ctx);
     return 0;
