@@ -452,12 +452,17 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             const int res_wgs = (int)((g.nmb * 6 + 31) / 32);            // k_residual8 workgroups (32 blocks) per frame
             const unsigned n_serial8 = 8u * (unsigned)((Gi + 7) / 8);
             const int st_ = xcd_slices(Gi, tiles), sr_ = xcd_slices(Gi, res_wgs);
+            // four-state search: a run of tiles per workgroup once one-per-tile would mean more than about 4096 workgroups,
+            // which in the usual case (no flag up) do nothing but get dispatched
+            int run = (int)(((long long)Gi * tiles + 4095) / 4096);
+            run = run < 1 ? 1 : (run > 32 ? 32 : run);
+            const int runs = (tiles + run - 1) / run, sf_ = xcd_slices(Gi, runs);
             launch_timed(ctx, ICSP_K_ME, sk, [&] {
-                hipLaunchKernelGGL((k_me<false>), dim3(xcd_grid(Gi, tiles, st_)), dim3(256), 0, sk, g, fs, b, tiles, st_);
-                if (!fused) hipLaunchKernelGGL((k_me<true>), dim3(xcd_grid(Gi, tiles, st_)), dim3(256), 0, sk, g, fs, b, tiles, st_);
+                hipLaunchKernelGGL((k_me<false>), dim3(xcd_grid(Gi, tiles, st_)), dim3(256), 0, sk, g, fs, b, tiles, st_, 1);
+                if (!fused) hipLaunchKernelGGL((k_me<true>), dim3(xcd_grid(Gi, runs, sf_)), dim3(256), 0, sk, g, fs, b, tiles, sf_, run);
             });
             launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
-                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, tiles, st_)), dim3(256), serial_lds, sk, g, fs, b, (int)n_serial8, tiles, st_);
+                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, runs, sf_)), dim3(256), serial_lds, sk, g, fs, b, (int)n_serial8, runs, sf_, run, tiles);
                 else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
             });
             launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(Gi, res_wgs, sr_)), dim3(256), 0, sk, g, fs, b, 0, 6, 1, res_wgs, sr_); });
