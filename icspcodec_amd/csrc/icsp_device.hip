@@ -408,10 +408,10 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             ctx->st_ahead = false;
         }
         launch_timed(ctx, ICSP_K_INTRA_LUMA, st, [&] { launch_intra_luma(ctx, g, fs, b, G, st); });
-        const int cwgs = (int)((g.nmb * 2 + 31) / 32);                // k_residual8 workgroups (32 blocks) per frame, chroma only
+        const int cwgs = ((g.nmb + 3) / 4 + 3) / 4;                   // k_residual8 workgroups per frame, chroma waves only
         launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
-        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(G, cwgs, sc_)), dim3(256), 0, s2, g, fs, b, 4, 2, 0, cwgs, sc_); });
+        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(G, cwgs, sc_)), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         ctx->s2_dirty = true;
         if (!lazy) join_s2(ctx);
     }
@@ -449,7 +449,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             // its staging loops
             const bool fused = g.nmb < 2048 && !ctx->no_fuse;
             const int tiles = ((g.sw + 1) / 2) * ((g.sh + 1) / 2);      // 2x2 macroblock tiles, one search workgroup each
-            const int res_wgs = (int)((g.nmb * 6 + 31) / 32);            // k_residual8 workgroups (32 blocks) per frame
+            const int res_wgs = ((g.nmb + 1) / 2 + (g.nmb + 3) / 4 + 3) / 4;     // k_residual8 workgroups per frame: luma + chroma waves
             const unsigned n_serial8 = 8u * (unsigned)((Gi + 7) / 8);
             const int st_ = xcd_slices(Gi, tiles), sr_ = xcd_slices(Gi, res_wgs);
             // four-state search: a run of tiles per workgroup once one-per-tile would mean more than about 4096 workgroups,
@@ -465,7 +465,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
                 if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, runs, sf_)), dim3(256), serial_lds, sk, g, fs, b, (int)n_serial8, runs, sf_, run, tiles);
                 else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
             });
-            launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(Gi, res_wgs, sr_)), dim3(256), 0, sk, g, fs, b, 0, 6, 1, res_wgs, sr_); });
+            launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(Gi, res_wgs, sr_)), dim3(256), 0, sk, g, fs, b, 1, res_wgs, sr_); });
         }
         if (!any) break;
     }
