@@ -443,7 +443,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             hipStream_t sk = k == 0 ? st : ctx->pstream[k];
             FrameSel fs{ first + g0 * L + i, L, Gi };
             const long long nmbs = (long long)Gi * g.nmb, nblk = nmbs * 6;
-            const size_t serial_lds = ((size_t)g.nmb * 15 + 15) & ~(size_t)15;
+            const size_t serial_lds = serial_lds_bytes(g.nmb, g.sw, g.sh);
             // small frames: the four-state search rides in the serial kernel's launch (one kernel boundary less per step;
             // nobody waits inside that launch, see k_serial_fused); else two launches, the serial one with 1024 threads for
             // its staging loops
