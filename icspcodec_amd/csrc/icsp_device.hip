@@ -9,15 +9,18 @@
 // ENC = /root/reference/source/encoder/ICSP_Codec_Encoder_source.cpp.
 //
 // Arithmetic contract: DCT/IDCT accumulate in IEEE double in the reference's index order
-// with separate multiply and add.  This file MUST be compiled with -ffp-contract=off (build() greps the ISA for
-// v_fma_f64 / v_fmac_f64).  Only bit-safe shortcuts are taken: x*1.0 is skipped, terms whose integer factor is zero
-// for the whole block are skipped (they add +-0 to a sum that started at +0).
+// with separate multiply and add.  This file MUST be compiled with -ffp-contract=off (build() greps the ISA of a
+// -DICSP_NO_FMA compile for v_fma_f64 / v_fmac_f64: the compiler must make none).  Only bit-safe shortcuts are taken: x*1.0
+// is skipped, terms whose integer factor is zero for the whole block are skipped (they add +-0 to a sum that started at
+// +0), and the first pass of each transform, whose products are exact, uses explicit fused multiply-adds (icsp_blk8.hip.inc,
+// proof against the reference's object code: oracle/fma_proof.c).
 //
 // Mapping (icsp_blk8.hip.inc): 8 lanes per 8x8 block for the throughput kernels (a lane owns one row or column, 8 blocks
-// per wave), 32 lanes per block for the latency-bound intra kernel; the two 1-D passes of each transform exchange data
-// through a 528-byte LDS tile per block.
-// Pieces: icsp_me.hip.inc (motion search, per-frame serial kernel with the DC-DPCM chains), icsp_blk8.hip.inc (transform
-// chain, k_residual8, k_intra_luma32), icsp_pack.hip.inc (bit packer), icsp_dec.hip.inc (decoder, §8 f4);
+// per wave; also the intra kernel's throughput form), 32 lanes per block for the latency-bound intra kernel; the two 1-D
+// passes of each transform exchange data through a 528-byte LDS tile per block.
+// Pieces: icsp_me.hip.inc (motion search over 2x2-macroblock tiles, per-frame serial kernel with the DC-DPCM chains,
+// last-arriver hand-off of the fused launch), icsp_blk8.hip.inc (transform chain, k_residual8, k_intra_luma32,
+// k_intra_luma8), icsp_pack.hip.inc (bit packer), icsp_dec.hip.inc (decoder, §8 f4);
 // the host half of the ABI (bit writer / assembler / parser) is icsp_bitstream.cpp.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
