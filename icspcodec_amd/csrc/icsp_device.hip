@@ -268,6 +268,12 @@ struct icsp_ctx {
     // cross-stream events at all; the join is deferred until something reads results (s2_dirty), the fork happens only
     // after other work was queued on `stream` (st_ahead) or when an outside producer uses the stream (always_sync)
     bool s2_dirty, st_ahead, always_sync;
+    // IPPP batches: every GOP group is a chain of its own (I frames, then its P steps) on its own stream, and consecutive
+    // encodes of the SAME range keep the chains independent across calls (no join, no fork: a slot is only ever touched by its
+    // group's stream).  p_dirty: the extra group streams carry work `stream` has not been ordered after yet; last_first /
+    // last_n: the range that work belongs to.
+    bool p_dirty;
+    int last_first, last_n;
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
     int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
     int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
@@ -379,14 +385,22 @@ int intra_waves_needed(const Geo& g)
     return (widest + 1) / 2;
 }
 
-void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st);
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st);
 
+// Orders `stream` after everything queued on the context's other streams (chroma stream, GOP-group streams): called by whatever
+// reads results, uploads, or encodes a different range.
 void join_s2(icsp_ctx* ctx)
 {
-    if (!ctx->s2_dirty) return;
-    hipEventRecord(ctx->ev_join, ctx->stream2);
-    hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
-    ctx->s2_dirty = false;
+    if (ctx->s2_dirty) {
+        hipEventRecord(ctx->ev_join, ctx->stream2);
+        hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+        ctx->s2_dirty = false;
+    }
+    if (ctx->p_dirty) {
+        for (int k = 1; k < kMaxPGroups; k++)
+            if (ctx->pstream[k]) { hipEventRecord(ctx->ev_pjoin[k], ctx->pstream[k]); hipStreamWaitEvent(ctx->stream, ctx->ev_pjoin[k], 0); }
+        ctx->p_dirty = false;
+    }
 }
 
 int encode_range(icsp_ctx* ctx, int first, int n)
@@ -397,55 +411,84 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     if (n == 0) return 0;
     DevBufs b = ctx->b;
     if (!ctx->keep_coef) b.coef = nullptr;
-    hipStream_t st = ctx->stream;
+    hipStream_t st = ctx->stream, s2 = ctx->stream2;
     const int G = (n + L - 1) / L;
-    // ---- step 0: the I frame of every GOP.  Chroma of an I frame does not depend on its luma (no pixel prediction,
-    //      ENC:4347-4349), so its three kernels run on a second stream beside the latency-bound luma wavefront kernel.
-    {
+    const int cwgs = ((g.nmb + 3) / 4 + 3) / 4;                       // k_residual8 workgroups per frame, chroma waves only
+    // GOP groups (L > 1): a P step is a chain of dependent kernels of which the serial one is latency-bound (one workgroup
+    // per frame) and leaves most of the chip idle, so the GOPs are split into groups, each running its own chain on its own
+    // stream: one group's serial kernel overlaps the others' search and residual kernels.  Groups touch disjoint frames,
+    // hence disjoint slots of every buffer.
+    int NG = ctx->p_groups;
+    if (NG > G / 4) NG = G / 4;                        // keep every group's launches wide enough to be worth splitting
+    if (NG < 1 || L == 1) NG = 1;
+    auto group_lo = [&](int k) { return (int)((long long)G * k / NG); };
+    if (L == 1) {
+        // ---- all-intra: the I frame of every GOP.  Chroma of an I frame does not depend on its luma (no pixel prediction,
+        //      ENC:4347-4349), so its kernels run on a second stream beside the latency-bound luma wavefront kernel.
         FrameSel fs{ first, L, G };
-        hipStream_t s2 = ctx->stream2;
-        const bool lazy = (L == 1) && !ctx->always_sync;
+        const bool lazy = !ctx->always_sync;
         if (!lazy || ctx->st_ahead) {
             hipEventRecord(ctx->ev_fork, st);
             hipStreamWaitEvent(s2, ctx->ev_fork, 0);
             ctx->st_ahead = false;
         }
-        launch_timed(ctx, ICSP_K_INTRA_LUMA, st, [&] { launch_intra_luma(ctx, g, fs, b, G, st); });
-        const int cwgs = ((g.nmb + 3) / 4 + 3) / 4;                   // k_residual8 workgroups per frame, chroma waves only
+        launch_timed(ctx, ICSP_K_INTRA_LUMA, st, [&] { launch_intra_luma(ctx, g, fs, b, G, G, st); });
         launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
         launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(G, cwgs, sc_)), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         ctx->s2_dirty = true;
         if (!lazy) join_s2(ctx);
+        HIPCHK(hipGetLastError());
+        return 0;
     }
-    if (L > 1) ctx->st_ahead = true;                   // the P steps below write what the next call's chroma kernels write
-    // ---- steps 1..L-1: the i-th P frame of every GOP that has one.  A P step is a chain of dependent kernels of which
-    //      k_frame_serial is latency-bound (one workgroup per frame) and leaves most of the chip idle: the GOPs are split
-    //      into groups, each running its own chain on its own stream, so one group's serial kernel overlaps the others'
-    //      search and residual kernels.  Groups touch disjoint frames, hence disjoint slots of every buffer.
-    int NG = ctx->p_groups;
-    if (NG > G / 4) NG = G / 4;                        // keep every group's launches wide enough to be worth splitting
-    if (NG < 1) NG = 1;
-    if (L > 1 && NG > 1) {
-        for (int k = 1; k < NG; k++)
-            if (!ctx->pstream[k]) {
-                HIPCHK(hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, ctx->prio_hi));
-                HIPCHK(hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming));
-            }
-        hipEventRecord(ctx->ev_fork, st);
-        for (int k = 1; k < NG; k++) hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0);
+    // ---- IPPP.  Every group is one chain on its stream: its I frames (luma), then its P steps.  The chroma of all I frames
+    // runs once on the chroma stream; every chain waits for it before its first P step (the luma kernel is ten times longer,
+    // so that wait is over before it is reached).  When this call encodes the same range as the one before and nothing else
+    // has touched the context since, the chains stay independent across the calls: a slot is only ever touched by its group's
+    // stream, so group 1 may still be finishing the previous pass while group 0 starts this one.  Anything else first joins
+    // everything onto `stream` (join_s2).
+    const bool same = ctx->p_dirty && !ctx->always_sync && ctx->last_first == first && ctx->last_n == n;
+    if (!same) join_s2(ctx);
+    for (int k = 1; k < NG; k++)
+        if (!ctx->pstream[k]) {
+            HIPCHK(hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, ctx->prio_hi));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming));
+        }
+    // the chroma kernels write what the previous pass's chains read (reconstruction of the I frames): after all of them
+    hipEventRecord(ctx->ev_fork, st);
+    hipStreamWaitEvent(s2, ctx->ev_fork, 0);
+    for (int k = 1; k < NG; k++) {
+        if (same) { hipEventRecord(ctx->ev_pjoin[k], ctx->pstream[k]); hipStreamWaitEvent(s2, ctx->ev_pjoin[k], 0); }
+        else hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0);      // a chain starts after what was queued on `stream` (uploads ...)
     }
+    {
+        FrameSel fs{ first, L, G };
+        launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
+        const int sc_ = xcd_slices(G, cwgs);
+        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(G, cwgs, sc_)), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
+        hipEventRecord(ctx->ev_join, s2);
+    }
+    for (int k = 0; k < NG; k++) {
+        const int g0 = group_lo(k), g1 = group_lo(k + 1);
+        hipStream_t sk = k == 0 ? st : ctx->pstream[k];
+        FrameSel fs{ first + g0 * L, L, g1 - g0 };
+        launch_timed(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fs, b, g1 - g0, G, sk); });
+        hipStreamWaitEvent(sk, ctx->ev_join, 0);
+    }
+    ctx->s2_dirty = false;                             // `stream` is ordered after the chroma stream's work (the wait above)
+    ctx->st_ahead = true;
+    ctx->p_dirty = NG > 1;
+    ctx->last_first = first; ctx->last_n = n;
     for (int i = 1; i < L; i++) {
         bool any = false;
         for (int k = 0; k < NG; k++) {
-            const int g0 = (int)((long long)G * k / NG), g1 = (int)((long long)G * (k + 1) / NG);
+            const int g0 = group_lo(k), g1 = group_lo(k + 1);
             int Gi = 0;
             for (int gop = g0; gop < g1; gop++) if (gop * L + i < n) Gi++;
             if (Gi == 0) continue;
             any = true;
             hipStream_t sk = k == 0 ? st : ctx->pstream[k];
             FrameSel fs{ first + g0 * L + i, L, Gi };
-            const long long nmbs = (long long)Gi * g.nmb, nblk = nmbs * 6;
             const size_t serial_lds = serial_lds_bytes(g.nmb, g.sw, g.sh);
             // small frames: the four-state search rides in the serial kernel's launch (one kernel boundary less per step;
             // nobody waits inside that launch, see k_serial_fused); else two launches, the serial one with 1024 threads for
@@ -472,8 +515,6 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         }
         if (!any) break;
     }
-    if (L > 1 && NG > 1)
-        for (int k = 1; k < NG; k++) { hipEventRecord(ctx->ev_pjoin[k], ctx->pstream[k]); hipStreamWaitEvent(st, ctx->ev_pjoin[k], 0); }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -537,7 +578,8 @@ template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const Dev
     hipLaunchKernelGGL((k_intra_luma8<NW>), dim3(G), dim3(NW * 64), 0, st, g, fs, b);
 }
 
-void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
+// G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st)
 {
     // 32-lane form: two blocks per wave.  `need` waves cover the widest wavefront step in one round.
     // With at most one I frame per CU the kernel is pure latency: use `need` waves.  With more frames than CUs, cap at 8
@@ -548,7 +590,7 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     const int need = ctx->intra_waves;
     const int need8 = (need * 2 + 7) / 8;                           // waves of eight blocks for the widest step
     int form = ctx->force_intra_form;
-    if (!form) form = (G > 2 * ctx->n_cu || need > 16) ? 8 : 32;
+    if (!form) form = (G_all > 2 * ctx->n_cu || need > 16) ? 8 : 32;
     if (form == 8) {
         const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : need8;
         if (nw <= 1)       launch_intra8<1>(g, fs, b, G, st);
@@ -561,7 +603,7 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
         else               launch_intra8<16>(g, fs, b, G, st);
         return;
     }
-    const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : (G > ctx->n_cu ? (need < 8 ? need : 8) : need);
+    const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : (G_all > ctx->n_cu ? (need < 8 ? need : 8) : need);
     if (nw <= 2)       hipLaunchKernelGGL((k_intra_luma32<2, 1>), dim3(G), dim3(128), 0, st, g, fs, b);
     else if (nw <= 4)  hipLaunchKernelGGL((k_intra_luma32<4, 1>), dim3(G), dim3(256), 0, st, g, fs, b);
     else if (nw <= 6)  hipLaunchKernelGGL((k_intra_luma32<6, 3>), dim3(G), dim3(384), 0, st, g, fs, b);
@@ -644,6 +686,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0;
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
+    ctx->p_dirty = false; ctx->last_first = -1; ctx->last_n = -1;
     int no_fuse = 0;
     ctx->force_intra_nw = 0; ctx->force_intra_form = 0;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
