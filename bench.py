@@ -405,8 +405,13 @@ def main():
             t0 = time.perf_counter()
             # relative input name: the output prefix is the input PATH up to its first '_' (encoder_main.cpp:10-17), and a
             # temporary directory's name may contain one
-            r = subprocess.run([enc_bin, "-i", os.path.basename(path), "-n", str(NFRAMES), "-q", "16", "--intraPeriod", "0", "--stats"], cwd=tmp,
-                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            def run_enc(args):
+                """icsp_enc as a child process, bounded: a stuck run is reported, never waited for."""
+                try:
+                    return subprocess.run([enc_bin] + args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+                except subprocess.TimeoutExpired as e:
+                    return subprocess.CompletedProcess(e.cmd, "timeout", e.stdout or b"", None)
+            r = run_enc(["-i", os.path.basename(path), "-n", str(NFRAMES), "-q", "16", "--intraPeriod", "0", "--stats"])
             wall = time.perf_counter() - t0
             out = r.stdout.decode(errors="replace")
             e2e = {"workload": "icsp_enc: foremanlike 300 f file -> .bin + test_yuv.yuv (tmpfs), all-intra QP16", "rc": r.returncode,
@@ -432,13 +437,18 @@ def main():
                 for _ in range(10):
                     fh.write(clip.tobytes())
             t0 = time.perf_counter()
-            r2 = subprocess.run([enc_bin, "-i", os.path.basename(long_path), "-n", "3000", "-q", "16", "--intraPeriod", "10", "--stats"], cwd=tmp,
-                                stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            r2 = run_enc(["-i", os.path.basename(long_path), "-n", "3000", "-q", "16", "--intraPeriod", "10", "--stats"])
             wall2 = time.perf_counter() - t0
             e2e["long_3000f_ippp"] = {"rc": r2.returncode, "wall_fps_incl_process_start_and_hip_init": round(3000 / wall2, 1),
                                       "stats": stats(r2.stdout.decode(errors="replace"))}
-            os.remove(long_path)
-            os.remove(os.path.join(tmp, "long_compCIF_16_16_10.bin"))
+            t0 = time.perf_counter()
+            r3 = run_enc(["-i", os.path.basename(long_path), "-n", "3000", "-q", "16", "--intraPeriod", "0", "--stats"])
+            wall3 = time.perf_counter() - t0
+            e2e["long_3000f_all_intra"] = {"rc": r3.returncode, "wall_fps_incl_process_start_and_hip_init": round(3000 / wall3, 1),
+                                           "stats": stats(r3.stdout.decode(errors="replace"))}
+            for f in (long_path, os.path.join(tmp, "long_compCIF_16_16_10.bin"), os.path.join(tmp, "long_compCIF_16_16_0.bin")):
+                if os.path.exists(f):
+                    os.remove(f)
 
     cpu = None if (a.no_cpu or world > 1 or rank != 0) else cpu_baseline()      # CPU baseline: rank 0 at N=1 only
     if world > 1:

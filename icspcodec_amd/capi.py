@@ -21,7 +21,7 @@ SYMBOLS = [
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
     "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
-    "icsp_bitstream_begin", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free",
+    "icsp_bitstream_begin", "icsp_bitstream_header", "icsp_pack_count", "icsp_pack_into", "icsp_prepare", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free", "icsp_host_register", "icsp_host_unregister",
 ]
 KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode"]
 
@@ -72,6 +72,13 @@ def load() -> C.CDLL:
         lib.icsp_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
         lib.icsp_write_bitstream.argtypes = [C.POINTER(Params), C.c_int, vp, vp, vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         lib.icsp_pack_bits.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.POINTER(C.c_uint64)]
+        lib.icsp_pack_count.argtypes = [vp, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        lib.icsp_pack_into.argtypes = [vp, C.c_int, C.c_int, C.c_uint64, vp, C.c_size_t]
+        lib.icsp_prepare.argtypes = [vp]
+        lib.icsp_bitstream_header.argtypes = [C.POINTER(Params), C.c_uint64, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.icsp_bitstream_end.argtypes = [vp, C.c_uint64]
+        lib.icsp_host_register.argtypes = [vp, C.c_size_t, C.c_int]
+        lib.icsp_host_unregister.argtypes = [vp]
         lib.icsp_bitstream_assemble.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), vp, C.c_size_t,
                                                 C.POINTER(C.c_size_t)]
         lib.icsp_parse_header.argtypes = [vp, C.c_size_t, C.POINTER(Params)]
@@ -118,6 +125,19 @@ def assemble_bitstream(width, height, qp_dc, qp_ac, intra_period, pieces) -> byt
     if rc:
         raise IcspError(lib.icsp_strerror(rc).decode())
     return out[: nbytes.value].tobytes()
+
+
+def finish_image(width, height, qp_dc, qp_ac, intra_period, image: np.ndarray, total_bits: int) -> bytes:
+    """Header + the reference's final byte on an image whose body icsp_pack_into has filled (icsp_bitstream_header/_end)."""
+    lib = load()
+    p = Params(width, height, qp_dc, qp_ac, intra_period)
+    n = C.c_size_t(0)
+    rc = lib.icsp_bitstream_header(C.byref(p), total_bits, _vp(image), image.size, C.byref(n))
+    if rc == 0:
+        rc = lib.icsp_bitstream_end(_vp(image), total_bits)
+    if rc:
+        raise RuntimeError(f"icsp_bitstream_header/end: {lib.icsp_strerror(rc).decode()}")
+    return image[: n.value].tobytes()
 
 
 def parse_header(bs: bytes) -> Params:
@@ -244,6 +264,19 @@ class Encoder:
         nbits = C.c_uint64(0)
         self._chk(self.lib.icsp_pack_bits(self.ctx, first, n, _vp(out), out.size, C.byref(nbits)), "icsp_pack_bits")
         return out[: (nbits.value + 7) // 8], nbits.value
+
+    def pack_count(self, first, n) -> int:
+        """Lengths + prefix sums of slots [first, first+n) on the device: the bit count of their string."""
+        nbits = C.c_uint64(0)
+        self._chk(self.lib.icsp_pack_count(self.ctx, first, n, C.byref(nbits)), "icsp_pack_count")
+        return nbits.value
+
+    def pack_into(self, first, n, at_bit, body_image: np.ndarray):
+        """Packs the range icsp_pack_count last measured at bit `at_bit` of the (zero-initialised) body image."""
+        self._chk(self.lib.icsp_pack_into(self.ctx, first, n, at_bit, _vp(body_image), body_image.size), "icsp_pack_into")
+
+    def prepare(self):
+        self._chk(self.lib.icsp_prepare(self.ctx), "icsp_prepare")
 
     def pack_bitstream(self, first, n) -> bytes:
         """The .bin image of slots [first, first+n) with the body packed on the device."""

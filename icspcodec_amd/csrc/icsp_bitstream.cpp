@@ -137,6 +137,16 @@ int icsp_bitstream_begin(const icsp_params_t* p, uint64_t total_bits, uint8_t* i
     return ICSP_OK;
 }
 
+int icsp_bitstream_header(const icsp_params_t* p, uint64_t total_bits, uint8_t* image, size_t cap, size_t* out_bytes)
+{
+    if (!p || !image || !out_bytes) return ICSP_ERR_UNENOUGH_PARAM;
+    const size_t body = (size_t)(total_bits / 8) + 1;
+    if (cap < 14 + body + 1) return ICSP_ERR_RANGE;
+    write_header(p, image);
+    *out_bytes = 14 + body;
+    return ICSP_OK;
+}
+
 // After every piece is placed: the reference shifts bits into each byte from the right, so a final partial byte holds its
 // bits right-aligned (ENC:4956).
 int icsp_bitstream_end(uint8_t* image, uint64_t total_bits)

@@ -284,6 +284,9 @@ struct icsp_ctx {
     DevBufs b;
     PackBufs pk;                      // device bit packer scratch + body buffer, allocated on first icsp_pack_bits
     size_t pk_cap;                    // bytes of pk.out
+    uint8_t* pk_host;                 // pinned: total bits of the last count (8 bytes) | head bytes at 64 | tail bytes at 192
+    int pk_first, pk_n;               // the range icsp_pack_count last measured (-1: none)
+    unsigned long long pk_total;      //   and its bits
     uint8_t* d_frames;
     bool keep_coef, profiling;
     unsigned prof_mask;               // which kernels get HIP events (icsp_profile_enable's argument, bit k = kernel k)
@@ -403,6 +406,17 @@ void join_s2(icsp_ctx* ctx)
     }
 }
 
+// the streams of GOP groups 1.. are created by the first encode that needs them (a stream costs 2-10 ms), or by icsp_prepare
+int group_streams(icsp_ctx* ctx, int ng)
+{
+    for (int k = 1; k < ng && k < kMaxPGroups; k++)
+        if (!ctx->pstream[k]) {
+            HIPCHK(hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, ctx->prio_hi));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming));
+        }
+    return 0;
+}
+
 int encode_range(icsp_ctx* ctx, int first, int n)
 {
     const Geo& g = ctx->g;
@@ -449,11 +463,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // everything onto `stream` (join_s2).
     const bool same = ctx->p_dirty && !ctx->always_sync && ctx->last_first == first && ctx->last_n == n;
     if (!same) join_s2(ctx);
-    for (int k = 1; k < NG; k++)
-        if (!ctx->pstream[k]) {
-            HIPCHK(hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, ctx->prio_hi));
-            HIPCHK(hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming));
-        }
+    if (int rc = group_streams(ctx, NG)) return rc;
     // the chroma kernels write what the previous pass's chains read (reconstruction of the I frames): after all of them
     hipEventRecord(ctx->ev_fork, st);
     hipStreamWaitEvent(s2, ctx->ev_fork, 0);
@@ -647,6 +657,21 @@ void* icsp_host_alloc(size_t bytes)
 
 void icsp_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+int icsp_host_register(void* p, size_t bytes, int read_only)
+{
+    if (!p || !bytes) return ICSP_ERR_UNENOUGH_PARAM;
+    const unsigned flags = hipHostRegisterPortable | (read_only ? hipHostRegisterReadOnly : 0u);
+    if (hipHostRegister(p, bytes, flags) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
+    return ICSP_OK;
+}
+
+int icsp_host_unregister(void* p)
+{
+    if (!p) return ICSP_ERR_UNENOUGH_PARAM;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
+    return ICSP_OK;
+}
+
 const char* icsp_kernel_name(int k)
 {
     static const char* names[ICSP_K_COUNT] = { "k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode" };
@@ -683,7 +708,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->n_cu = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ctx->n_cu = v; }
     memset(&ctx->b, 0, sizeof(ctx->b));
-    memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0;
+    memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0; ctx->pk_host = nullptr; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
     ctx->p_dirty = false; ctx->last_first = -1; ctx->last_n = -1;
@@ -754,6 +779,7 @@ int icsp_destroy(icsp_ctx_t* ctx)
     hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.me_sums); hipFree(ctx->b.me_flag); hipFree(ctx->b.me_done);
     hipFree(ctx->b.dcpred); hipFree(ctx->b.coef);
     hipFree(ctx->pk.grp_bits); hipFree(ctx->pk.grp_off); hipFree(ctx->pk.chunk_bits); hipFree(ctx->pk.chunk_base); hipFree(ctx->pk.out);
+    if (ctx->pk_host) hipHostFree(ctx->pk_host);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
@@ -835,34 +861,51 @@ int icsp_decode_resident(icsp_ctx_t* ctx, int first, int n)
     return decode_range(ctx, first, n);
 }
 
-int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap, uint64_t* nbits)
+// ---- device bit packer (icsp_pack.hip.inc).  Two steps: lengths + scans (the host learns the number of bits), then the
+// packing itself at a bit phase the host chooses.
+static int pack_alloc(icsp_ctx* ctx)
 {
-    if (!ctx || !body || !nbits) return ICSP_ERR_UNENOUGH_PARAM;
-    if (int rc = check_range(ctx, first, n)) return rc;
-    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
-    if (first % L != 0) return ICSP_ERR_RANGE;
-    *nbits = 0;
-    if (n == 0) return ICSP_OK;
-    HIPCHK(hipSetDevice(ctx->device));
-    join_s2(ctx);
+    if (ctx->pk.out) return ICSP_OK;
     const Geo& g = ctx->g;
     const long long cap_grps = ((long long)ctx->max_frames * g.nmb * 6 + kGrpUnits - 1) / kGrpUnits;
-    if (!ctx->pk.out) {
-        const size_t chunks = (size_t)((cap_grps + kChunkGrps - 1) / kChunkGrps);
-        ctx->pk_cap = (icsp_bitstream_bound(&ctx->p, ctx->max_frames) + 16 + 3) & ~(size_t)3;
-        hipError_t e = hipSuccess;
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.grp_bits, (size_t)cap_grps * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.grp_off, (size_t)cap_grps * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.chunk_bits, chunks * 8);
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.chunk_base, (chunks + 1) * 8);
-        if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.out, ctx->pk_cap);
-        if (e != hipSuccess) {
-            hipFree(ctx->pk.grp_bits); hipFree(ctx->pk.grp_off); hipFree(ctx->pk.chunk_bits); hipFree(ctx->pk.chunk_base); hipFree(ctx->pk.out);
-            memset(&ctx->pk, 0, sizeof(ctx->pk));
-            ctx->err = std::string("hipMalloc bit packer: ") + hipGetErrorString(e);
-            return ICSP_ERR_MEM_ALLOC;
-        }
+    const size_t chunks = (size_t)((cap_grps + kChunkGrps - 1) / kChunkGrps);
+    ctx->pk_cap = (icsp_bitstream_bound(&ctx->p, ctx->max_frames) + 64 + 16 + 3) & ~(size_t)3;     // + the byte phase of icsp_pack_into
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.grp_bits, (size_t)cap_grps * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.grp_off, (size_t)cap_grps * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.chunk_bits, chunks * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.chunk_base, (chunks + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.out, ctx->pk_cap);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->pk_host, 256, hipHostMallocDefault);     // total bits | head | tail
+    if (e != hipSuccess) {
+        hipFree(ctx->pk.grp_bits); hipFree(ctx->pk.grp_off); hipFree(ctx->pk.chunk_bits); hipFree(ctx->pk.chunk_base); hipFree(ctx->pk.out);
+        if (ctx->pk_host) hipHostFree(ctx->pk_host);
+        memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_host = nullptr;
+        ctx->err = std::string("hipMalloc bit packer: ") + hipGetErrorString(e);
+        return ICSP_ERR_MEM_ALLOC;
     }
+    return ICSP_OK;
+}
+
+static int pack_check(icsp_ctx* ctx, int first, int n)
+{
+    if (int rc = check_range(ctx, first, n)) return rc;
+    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
+    return (first % L != 0) ? ICSP_ERR_RANGE : ICSP_OK;
+}
+
+int icsp_pack_count(icsp_ctx_t* ctx, int first, int n, uint64_t* nbits)
+{
+    if (!ctx || !nbits) return ICSP_ERR_UNENOUGH_PARAM;
+    if (int rc = pack_check(ctx, first, n)) return rc;
+    *nbits = 0;
+    ctx->pk_first = -1;
+    if (n == 0) { ctx->pk_first = first; ctx->pk_n = 0; ctx->pk_total = 0; return ICSP_OK; }
+    HIPCHK(hipSetDevice(ctx->device));
+    join_s2(ctx);
+    if (int rc = pack_alloc(ctx)) return rc;
+    const Geo& g = ctx->g;
+    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
     hipStream_t st = ctx->stream;
     const long long ngrp = ((long long)n * g.nmb * 6 + kGrpUnits - 1) / kGrpUnits;
     const int nchunk = (int)((ngrp + kChunkGrps - 1) / kChunkGrps);
@@ -872,20 +915,133 @@ int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap,
         hipLaunchKernelGGL(k_bits_count, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, g, first, n, L, ngrp, b, pk);
         hipLaunchKernelGGL(k_bits_scan, dim3(nchunk), dim3(256), 0, st, ngrp, pk);
         hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(256), 0, st, nchunk, pk);
-        hipLaunchKernelGGL(k_pack_zero, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, st, ngrp, pk);
-        hipLaunchKernelGGL(k_pack, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, g, first, n, L, ngrp, b, pk);
     });
     HIPCHK(hipGetLastError());
-    unsigned long long total = 0;
-    HIPCHK(hipMemcpyAsync(&total, pk.chunk_base + nchunk, 8, hipMemcpyDeviceToHost, st));
+    unsigned long long* total = (unsigned long long*)ctx->pk_host;
+    HIPCHK(hipMemcpyAsync(total, pk.chunk_base + nchunk, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    ctx->pk_first = first; ctx->pk_n = n; ctx->pk_total = *total;
+    *nbits = *total;
+    return ICSP_OK;
+}
+
+// the packing kernels for the range icsp_pack_count last measured, the string starting at bit `sh` (0..7) of pk.out
+static int pack_write(icsp_ctx* ctx, int first, int n, unsigned sh)
+{
+    const Geo& g = ctx->g;
+    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
+    hipStream_t st = ctx->stream;
+    const long long ngrp = ((long long)n * g.nmb * 6 + kGrpUnits - 1) / kGrpUnits;
+    const DevBufs& b = ctx->b;
+    const PackBufs& pk = ctx->pk;
+    launch_timed(ctx, ICSP_K_PACK, st, [&] {
+        hipLaunchKernelGGL(k_pack_zero, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, st, ngrp, pk, sh);
+        hipLaunchKernelGGL(k_pack, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, g, first, n, L, ngrp, b, pk, sh);
+    });
+    HIPCHK(hipGetLastError());
+    return ICSP_OK;
+}
+
+int icsp_pack_into(icsp_ctx_t* ctx, int first, int n, uint64_t at_bit, uint8_t* body_image, size_t cap)
+{
+    if (!ctx || !body_image) return ICSP_ERR_UNENOUGH_PARAM;
+    if (int rc = pack_check(ctx, first, n)) return rc;
+    if (ctx->pk_first != first || ctx->pk_n != n) { ctx->err = "icsp_pack_into without icsp_pack_count of the same range"; return ICSP_ERR_RANGE; }
+    if (ctx->pk_total == 0) return ICSP_OK;
+    const unsigned sh = (unsigned)(at_bit & 7);
+    const size_t nb = (size_t)((sh + ctx->pk_total + 7) / 8), b0 = (size_t)(at_bit >> 3);
+    if (b0 + nb > cap || b0 + nb < b0) return ICSP_ERR_RANGE;
+    HIPCHK(hipSetDevice(ctx->device));
+    // The string is packed at the byte phase (mod 64) and bit phase it has in the image, so that device byte j and its place
+    // in the image are congruent mod 64 and the bulk goes as one aligned copy (DMA engines crawl on odd addresses: 6 GB/s
+    // instead of 57 measured).  The ragged head and tail (< 64 bytes each) come back through a pinned scratch; their
+    // outermost bytes may be shared with the neighbouring strings and are OR-ed in, the rest is stored.
+    uint8_t* dst = body_image + b0;
+    const size_t A = (size_t)((uintptr_t)dst & 63);
+    if (int rc = pack_write(ctx, first, n, (unsigned)(A * 8 + sh))) return rc;
+    hipStream_t st = ctx->stream;
+    const uint8_t* out = (const uint8_t*)ctx->pk.out;              // device byte A + j  <->  dst[j]
+    const size_t lo = A, hi = A + nb;
+    size_t ilo = (lo + 1 + 63) & ~(size_t)63, ihi = (hi - 1) & ~(size_t)63;      // aligned interior, first and last byte excluded
+    if (ihi <= ilo) ilo = ihi = hi;                                // short string: everything through the scratch
+    const size_t nhead = std::min(ilo, hi) - lo, ntail = hi - std::max(ihi, lo + nhead);
+    uint8_t* head = ctx->pk_host + 64;
+    uint8_t* tail = ctx->pk_host + 192;                           // (head: up to 127 bytes when there is no interior)
+    if (ihi > ilo) HIPCHK(hipMemcpyAsync(dst + (ilo - lo), out + ilo, ihi - ilo, hipMemcpyDeviceToHost, st));
+    if (nhead) HIPCHK(hipMemcpyAsync(head, out + lo, nhead, hipMemcpyDeviceToHost, st));
+    if (ntail) HIPCHK(hipMemcpyAsync(tail, out + hi - ntail, ntail, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t j = 0; j < nhead; j++) {
+        if (j == 0 || j == nb - 1) __atomic_fetch_or(&dst[j], head[j], __ATOMIC_RELAXED);
+        else dst[j] = head[j];
+    }
+    for (size_t j = 0; j < ntail; j++) {
+        const size_t d = nb - ntail + j;
+        if (d == nb - 1) __atomic_fetch_or(&dst[d], tail[j], __ATOMIC_RELAXED);
+        else dst[d] = tail[j];
+    }
+    if (ctx->profiling) collect_profile(ctx);
+    return ICSP_OK;
+}
+
+int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap, uint64_t* nbits)
+{
+    if (!ctx || !body || !nbits) return ICSP_ERR_UNENOUGH_PARAM;
+    if (int rc = icsp_pack_count(ctx, first, n, nbits)) return rc;
+    const uint64_t total = *nbits;
+    if (total == 0) return ICSP_OK;
     const size_t nbytes = (size_t)((total + 7) / 8);
-    if (nbytes > cap) return ICSP_ERR_RANGE;
-    if (nbytes) HIPCHK(hipMemcpyAsync(body, pk.out, nbytes, hipMemcpyDeviceToHost, st));
+    if (nbytes > cap) { *nbits = 0; return ICSP_ERR_RANGE; }
+    if (int rc = pack_write(ctx, first, n, 0)) return rc;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemcpyAsync(body, ctx->pk.out, nbytes, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (ctx->profiling) collect_profile(ctx);
-    *nbits = total;
     return ICSP_OK;
+}
+
+// Everything an encode or pack creates on first use (the GOP-group streams, the packer's buffers, the kernels' first
+// launches) is created now, by encoding one GOP of black frames and packing it -- a host that times or pipelines its
+// batches calls this while it sets up (icsp_enc).  The frame store's first GOP is overwritten.
+int icsp_prepare(icsp_ctx_t* ctx)
+{
+    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
+    const int n = std::min(ctx->max_frames, std::max(L, 2 * L <= ctx->max_frames ? 2 * L : L));    // two GOPs when they fit: both group streams
+    join_s2(ctx);
+    if (L > 1 && ctx->max_frames >= 8 * L) {                        // batches of 8+ GOPs run as p_groups chains
+        if (int rc = group_streams(ctx, ctx->p_groups)) return rc;
+        for (int k = 1; k < ctx->p_groups; k++) HIPCHK(hipMemsetAsync(ctx->b.me_done, 0, sizeof(int), ctx->pstream[k]));    // first use of the queue
+        for (int k = 1; k < ctx->p_groups; k++) HIPCHK(hipStreamSynchronize(ctx->pstream[k]));
+    }
+    {   // the first DMA of a process in each direction costs about 6 ms inside the hipMemcpyAsync call, whatever its size
+        // (a transfer queue is set up); the device-to-host one only counts towards memory pinned by hipHostRegister
+        const size_t nb = std::min<size_t>((size_t)1 << 20, (size_t)ctx->max_frames * ctx->g.fsz);
+        void* h = aligned_alloc(4096, (nb + 4095) & ~(size_t)4095);
+        if (h) {
+            memset(h, 0, nb);
+            if (hipHostRegister(h, nb, hipHostRegisterPortable) == hipSuccess) {
+                (void)hipMemcpyAsync(ctx->d_frames, h, nb, hipMemcpyHostToDevice, ctx->stream);
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipMemcpyAsync(h, ctx->d_frames, nb, hipMemcpyDeviceToHost, ctx->stream);
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipHostUnregister(h);
+            } else (void)hipGetLastError();
+            free(h);
+        }
+    }
+    HIPCHK(hipMemsetAsync(ctx->d_frames, 0, (size_t)n * ctx->g.fsz, ctx->stream));
+    ctx->st_ahead = true;
+    if (int rc = encode_range(ctx, 0, n)) return rc;
+    uint64_t bits = 0;
+    const int npk = (n / L) * L;
+    if (npk > 0) {
+        if (int rc = icsp_pack_count(ctx, 0, npk, &bits)) return rc;
+        if (int rc = pack_write(ctx, 0, npk, 0)) return rc;
+    }
+    ctx->pk_first = -1;
+    return icsp_sync(ctx);
 }
 
 int icsp_encode_gop(icsp_ctx_t* ctx, const uint8_t* yuv, int n, int16_t* levels, uint8_t* acflag, uint8_t* mpm, int8_t* mvd, uint8_t* recon)

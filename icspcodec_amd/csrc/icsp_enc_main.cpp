@@ -12,17 +12,25 @@
 // (include/icsp_hip.h).
 //
 // Streaming layout (load -> encode -> write of the reference, ENC:247-283 / 217-245 / 6376-6421, as a pipeline): the clip is
-// cut into shards of whole closed GOPs; every shard has a host thread and a context of its own (several per device), and
-// does  pread -> pinned buffer -> H2D -> kernels -> device bit packer -> D2H (bits + reconstruction) -> pwrite  for its
-// frames.  The shards run at different phases, so one's transfers and file I/O overlap with another's kernels; nothing is
-// read or written twice, and the output bytes do not depend on the number of shards.  The per-shard bit strings are placed
-// into the .bin image at their bit offsets by the shard threads (icsp_bitstream_place).
+// cut into shards of whole closed GOPs; every shard has a host thread and a context of its own and moves its frames through
+// the device in chunks of whole GOPs:  H2D -> kernels -> device bit packer -> D2H (bits + reconstruction).  The shards run
+// at different phases, so one's transfers overlap with another's kernels.
+//   * Mapped mode (default): the input file and test_yuv.yuv are mmap'ed and the mappings pinned (icsp_host_register), so the
+//     uploads read the page cache and the downloads write it by DMA -- the host copies nothing.  A helper thread maps the
+//     files and allocates the output's pages (MAP_POPULATE: the slowest host step, ~6 GB/s on tmpfs whatever the thread
+//     count) while the HIP runtime starts.
+//   * Staged mode (--staged, clips above the mapping cap, or when mapping / pinning is refused): pread -> pinned buffer ->
+//     device and device -> pinned buffer -> pwrite, per chunk.
+// Nothing is read or written twice and the output bytes do not depend on the mode, the chunk size or the number of shards.
+// The chunks' bit strings are placed into the (mmap'ed) .bin at their bit offsets by several threads (icsp_bitstream_place).
 //
 // Extensions use long options the reference rejects as unknown, so its own surface is unchanged:
 //   --hostpack      sequential bit writer on the host instead of the device packer (same bytes; for cross-checks)
 //   --gpus N        devices to shard over (default 1); --EnMultiThread N asks for N shards (the reference's N worker threads)
-//   --streams S     shards (contexts + host threads) per device when --EnMultiThread is not given (default: one per 150 CIF
-//                   frames' worth of macroblocks, at most 4)
+//   --streams S     workers (contexts + host threads) per device when --EnMultiThread is not given (default: one per
+//                   chunk, at most 3)
+//   --chunk F       frames per chunk (rounded up to whole GOPs; default: 512 CIF frames' worth of macroblocks)
+//   --staged        staging buffers instead of pinned file mappings
 //   --width W --height H   frame size (the reference hard-codes 352x288, encoder_main.cpp:20)
 //   --stats         one more output line at the end: "[icsp_enc]{json}" with the wall-clock split (bench.py's e2e leg)
 // Deliberate differences: the thread-pool mode also writes the .bin (the reference commented that call out,
@@ -33,10 +41,14 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -49,7 +61,8 @@ enum { SUCCESS = 0, UNENOUGH_PARAM, UNCORRECT_PARAM, FAIL_MEM_ALLOC };
 struct Options {
     char yuv_fname[256];
     int total_frames, qp_dc, qp_ac, intra_period, multi_thread_mode, nthreads;
-    int gpus, width, height, hostpack, streams, stats;
+    int gpus, width, height, hostpack, streams, stats, staged, chunk;
+    long long binest;
 };
 
 void print_help_message()
@@ -67,7 +80,9 @@ void print_help_message()
     printf("--intraPeriod: period of intra frame(0: All intra)\n");
     printf("--EnMultiThread: enable multi threading mode, also the number of thread(0~4, 0 is disable)\n");
     printf("--gpus : [MI355X build] number of GPUs to shard closed GOPs over (default 1)\n");
-    printf("--streams : [MI355X build] shards (host thread + context) per GPU (default up to 4)\n");
+    printf("--streams : [MI355X build] workers (host thread + context) per GPU (default up to 3)\n");
+    printf("--chunk : [MI355X build] frames per chunk moved through the device (default 512 CIF frames' worth)\n");
+    printf("--staged : [MI355X build] staging buffers instead of pinned mappings of the input and output files\n");
     printf("--hostpack : [MI355X build] pack the bitstream on the host instead of on the device (same bytes)\n");
     printf("--width, --height : [MI355X build] frame size, multiples of 16 (default 352x288)\n");
     printf("--stats : [MI355X build] print a final line with the wall-clock split\n");
@@ -106,6 +121,9 @@ int parsing_command(int argc, char* argv[], Options* cmd)
             else if (!strcmp(name, "height")) cmd->height = atoi(val);
             else if (!strcmp(name, "hostpack")) cmd->hostpack = 1;
             else if (!strcmp(name, "stats")) cmd->stats = 1;
+            else if (!strcmp(name, "staged")) cmd->staged = 1;
+            else if (!strcmp(name, "chunk")) cmd->chunk = atoi(val);
+            else if (!strcmp(name, "binest")) cmd->binest = atoll(val);
             else return UNCORRECT_PARAM;
         } else {
             if (o[1] == 'i') { strncpy(cmd->yuv_fname, val, 255); cmd->yuv_fname[255] = 0; }
@@ -118,17 +136,42 @@ int parsing_command(int argc, char* argv[], Options* cmd)
     return SUCCESS;
 }
 
-struct Piece { uint64_t bits; std::vector<uint8_t> bytes; };      // the bit string of one chunk
-struct Shard {
-    int device, first, count, rc;
-    std::string err;
-    std::vector<Piece> pieces;                             // in frame order
-    uint64_t bits;                                         // sum over the pieces
-    uint8_t* body; size_t body_cap; bool body_own;         // pinned staging: one chunk's bit string,
-    uint8_t* in; uint8_t* recon;                           //   frames and reconstruction
-    icsp_ctx_t* ctx;
-    double t_setup, t_read, t_gpu, t_write;
+// A chunk: whole GOPs that go through the device together.  Its bit string lands either straight in the .bin mapping
+// (direct) or in `bytes`, to be placed at the end.
+struct Chunk {
+    int first, count;
+    uint64_t bits, at;                                     // length and bit offset in the body (known when its turn has come)
+    bool direct;
+    std::vector<uint8_t> bytes;
 };
+// A worker: host thread + context (+ pinned buffers) that takes chunks from the queue.  --EnMultiThread N = N workers.
+struct Worker {
+    int device, rc, chunks;
+    std::string err;
+    icsp_ctx_t* ctx;
+    uint8_t* body; size_t body_cap;                        // pinned: one chunk's bit string, when it cannot go direct
+    uint8_t* stage;                                        // pinned staging for frames / reconstruction (staged mode only)
+    double t_setup, t_read, t_write, t_up, t_enc, t_count, t_turn, t_pack, t_down;
+};
+
+// One-shot gate: the helper thread opens it when the file mappings are settled, the main thread when the runtime is up.
+struct Gate {
+    std::mutex m; std::condition_variable cv; bool open = false;
+    void set() { { std::lock_guard<std::mutex> l(m); open = true; } cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> l(m); cv.wait(l, [&] { return open; }); }
+};
+// All workers start streaming together once every context and buffer exists: "init" ends when the last one arrives.
+struct Barrier {
+    std::mutex m; std::condition_variable cv; int waiting = 0, total = 0; double t_last = 0;
+};
+// The body's bit cursor: chunk c learns its offset when every chunk before it has reported its length.
+struct Cursor {
+    std::mutex m; std::condition_variable cv; int turn = 0; uint64_t bits = 0; bool failed = false;
+};
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
 
 double now()
 {
@@ -176,167 +219,287 @@ int main(int argc, char* argv[])
     const size_t fsz = (size_t)W * H * 3 / 2, nmb = (size_t)(W / 16) * (H / 16);
     if (n <= 0 || opt.qp_dc <= 0 || opt.qp_ac <= 0 || W % 16 || H % 16) print_error_message(UNCORRECT_PARAM, "parsing_command");
 
-    // YCbCrLoad (ENC:247-283): the file must hold n frames; the shards read their own parts
+    // YCbCrLoad (ENC:247-283): the file must hold n frames; the workers read their own parts
     const int fd_in = open(opt.yuv_fname, O_RDONLY);
     struct stat st;
     if (fd_in < 0 || fstat(fd_in, &st) != 0 || (uint64_t)st.st_size < (uint64_t)fsz * n) { printf("fail to load cif.yuv\n error from YCbCrLoad\n"); exit(-1); }
+    // checkResultFrames(..., SAVE_YUV) (ENC:6376-6413): every chunk's frames are written at their place in the file
+    const size_t total_bytes = fsz * (size_t)n;
+    const int fd_rec = open("test_yuv.yuv", O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd_rec >= 0 && ftruncate(fd_rec, (off_t)total_bytes) != 0) { /* pwrite extends the file anyway */ }
+    // makebitstream (ENC:4849-4900)
+    char name[512];
+    snprintf(name, sizeof(name), "%s_compCIF_%d_%d_%d.bin", prefix.c_str(), opt.qp_dc, opt.qp_ac, opt.intra_period);
+    const int fd_bin = open(name, O_RDWR | O_CREAT | O_TRUNC, 0644);
+    if (fd_bin < 0) { printf("fail to open compCIF.bin\n"); exit(-1); }
+    icsp_params_t params{ W, H, opt.qp_dc, opt.qp_ac, opt.intra_period };
 
-    // closed-GOP shards, one host thread + one context each (the analogue of encoding_thread, ENC:186-213).
-    // --EnMultiThread N: N shards; otherwise --gpus G (default 1) devices x --streams S (default 4) shards per device.  With
-    // fewer devices than asked for, shards share devices round-robin, so every option still works on a one-GPU box.
+    // Mapped mode: a helper maps the three files while the runtime starts -- allocating the pages of test_yuv.yuv and of the
+    // part of the .bin the stream is expected to need (the file is sized for the worst case, sparse) -- then pins them.
+    const size_t kMapCap = (size_t)8 << 30;                         // input + output above this are streamed through staging buffers
+    const bool want_map = !opt.staged && 2 * total_bytes <= kMapCap;
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    const size_t bin_cap = icsp_bitstream_bound(&params, n) + 2;    // worst case, header included
+    // (the part populated and pinned: 30 % of the input + 1 MB covers QP >= 8 on camera-like content; strings that end
+    //  beyond it come back through a pinned buffer and are placed by the host.  --binest BYTES overrides, for tests)
+    const size_t bin_guess = opt.binest > 0 ? (size_t)opt.binest : 14 + total_bytes * 3 / 10 + ((size_t)1 << 20);
+    const size_t bin_est = std::min(bin_cap, (bin_guess + page - 1) / page * page);
+    uint8_t* in_map = nullptr; uint8_t* out_map = nullptr;           // non-null only when mapped AND pinned
+    uint8_t* bin_map = nullptr;                                      // the .bin mapping (bin_cap bytes), pinned or not
+    bool bin_pinned = false;                                         //   its first bin_est bytes are populated and pinned
+    double t_map = 0, t_pin = 0;
+    Gate hip_up, maps_settled;
+    std::thread helper([&] {
+        if (want_map) {
+            const double t0 = now();
+            void* out_raw = MAP_FAILED;
+            if (fd_rec >= 0) out_raw = mmap(nullptr, total_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd_rec, 0);
+            void* in_raw = mmap(nullptr, total_bytes, PROT_READ, MAP_SHARED | MAP_POPULATE, fd_in, 0);
+            void* bin_raw = MAP_FAILED;
+            if (ftruncate(fd_bin, (off_t)bin_cap) == 0) bin_raw = mmap(nullptr, bin_cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd_bin, 0);
+            if (bin_raw != MAP_FAILED && madvise(bin_raw, bin_est, MADV_POPULATE_WRITE) != 0)
+                for (size_t o = 0; o < bin_est; o += page) ((volatile uint8_t*)bin_raw)[o] = 0;      // (kernels before 5.14)
+            t_map = now() - t0;
+            hip_up.wait();
+            const double t1 = now();
+            if (in_raw != MAP_FAILED && icsp_host_register(in_raw, total_bytes, 1) == ICSP_OK) in_map = (uint8_t*)in_raw;
+            if (out_raw != MAP_FAILED && icsp_host_register(out_raw, total_bytes, 0) == ICSP_OK) out_map = (uint8_t*)out_raw;
+            if (bin_raw != MAP_FAILED) { bin_map = (uint8_t*)bin_raw; bin_pinned = icsp_host_register(bin_raw, bin_est, 0) == ICSP_OK; }
+            t_pin = now() - t1;
+        }
+        maps_settled.set();
+    });
+
+    // Closed-GOP chunks in a queue, taken by workers: one host thread + one context each (the analogue of encoding_thread,
+    // ENC:186-213).  --EnMultiThread N: N workers; otherwise --gpus G (default 1) devices x --streams S workers per device.
+    // With fewer devices than asked for, workers share devices round-robin, so every option still works on a one-GPU box.
     const int L = opt.intra_period > 0 ? opt.intra_period : 1;
     const int ngop = (n + L - 1) / L;
     const int ndev_seen = icsp_device_count();                      // starts the HIP runtime
+    hip_up.set();
     const int ndev = ndev_seen > 0 ? ndev_seen : 1;
-    int nshard;
-    if (opt.multi_thread_mode > 0) nshard = opt.nthreads;
-    else if (opt.gpus > 0 && opt.streams <= 0) nshard = opt.gpus;   // --gpus N alone: N shards, as before
+    // a chunk: whole GOPs, by default as many frames as hold 512 CIF frames' macroblocks (at least one GOP)
+    const int chunk_target = opt.chunk > 0 ? opt.chunk : std::max(1, (int)(512 * 396 / nmb));
+    int chunk_gops = (chunk_target + L - 1) / L;
+    int nworker;
+    if (opt.multi_thread_mode > 0) nworker = opt.nthreads;
     else {
-        // setting a context up costs about as much as encoding 150 CIF frames (streams, pinned memory), so short clips get few
-        int per_dev = opt.streams > 0 ? opt.streams : std::min(4, std::max(1, (int)((uint64_t)n * nmb / (150 * 396))));
-        nshard = (opt.gpus > 0 ? opt.gpus : 1) * per_dev;
+        // default: up to three workers per device (measured on 3000 CIF frames: 1 worker 80 k, 2 workers 105 k, 3 workers
+        // 120 k frames/s; more add set-up time and nothing else), one per chunk on short clips
+        const int chunks_per_dev = (ngop + chunk_gops * std::max(1, opt.gpus) - 1) / (chunk_gops * std::max(1, opt.gpus));
+        const int per_dev = opt.streams > 0 ? opt.streams : std::max(1, std::min(3, chunks_per_dev));
+        nworker = (opt.gpus > 0 ? opt.gpus : 1) * per_dev;
     }
-    if (nshard > ngop) nshard = ngop;
-    if (nshard > 64) nshard = 64;
-    if (nshard < 1) nshard = 1;
-    std::vector<Shard> shards(nshard);
-    int g0 = 0;
-    for (int d = 0; d < nshard; d++) {
-        const int gcount = ngop / nshard + (d < ngop % nshard ? 1 : 0);
-        Shard& s = shards[d];
-        s.device = d % ndev; s.first = g0 * L;
-        s.count = std::min(n, (g0 + gcount) * L) - g0 * L;
-        s.rc = 0; s.bits = 0; s.body = nullptr; s.body_cap = 0; s.in = nullptr; s.recon = nullptr; s.ctx = nullptr; s.body_own = false;
-        s.t_setup = s.t_read = s.t_gpu = s.t_write = 0;
-        g0 += gcount;
+    nworker = std::max(1, std::min({ nworker, ngop, 64 }));
+    chunk_gops = std::max(1, std::min(chunk_gops, (ngop + nworker - 1) / nworker));     // every worker gets something to do
+    const int chunk = chunk_gops * L;
+    std::vector<Chunk> chunks;
+    for (int f = 0; f < n; f += chunk) { Chunk c; c.first = f; c.count = std::min(chunk, n - f); c.bits = c.at = 0; c.direct = false; chunks.push_back(std::move(c)); }
+    const int nchunks = (int)chunks.size();
+    std::vector<Worker> workers(nworker);
+    for (int d = 0; d < nworker; d++) {
+        Worker& w = workers[d];
+        w.device = d % ndev; w.rc = 0; w.chunks = 0; w.ctx = nullptr; w.body = nullptr; w.body_cap = 0; w.stage = nullptr;
+        w.t_setup = w.t_read = w.t_write = w.t_up = w.t_enc = w.t_count = w.t_turn = w.t_pack = w.t_down = 0;
     }
-    icsp_params_t params{ W, H, opt.qp_dc, opt.qp_ac, opt.intra_period };
-
-    // checkResultFrames(..., SAVE_YUV) (ENC:6376-6413): every shard writes its frames at their place in the file
-    const int fd_rec = open("test_yuv.yuv", O_WRONLY | O_CREAT | O_TRUNC, 0644);
-    if (fd_rec >= 0 && ftruncate(fd_rec, (off_t)(fsz * n)) != 0) { /* pwrite extends the file anyway */ }
 
     // --hostpack: bring levels/flags/vectors back and run the sequential writer on the host (kept for cross-checking).
     std::vector<int16_t> levels;
     std::vector<uint8_t> acflag, mpm;
     std::vector<int8_t> mvd;
     if (opt.hostpack) { levels.resize(nmb * 384 * n); acflag.resize(nmb * 6 * n); mpm.resize(nmb * 4 * n); mvd.resize(nmb * 2 * n); }
-    // A shard streams its frames through the device in chunks of whole GOPs (about 48 frames, 7 MB of CIF): the context's
-    // frame store and the pinned staging buffers are sized for one chunk, whatever the length of the clip.
-    int chunk = ((48 + L - 1) / L) * L;
-    double t_init_done = 0;
-    auto work = [&](Shard* s) {
+    Barrier ready; ready.total = nworker;
+    Cursor cursor;
+    std::atomic<int> next_chunk(0);
+    auto work = [&](Worker* w) {
         double t0 = now();
-        const int cmax = std::min(chunk, s->count);
-        s->rc = icsp_create(&s->ctx, &params, s->device, cmax);
-        if (s->rc) { s->err = icsp_strerror(s->rc); return; }
-        if (s == &shards[0]) t_init_done = now();                  // runtime up, code object loaded, first context built
-        // one pinned allocation (each costs milliseconds) carved into frames | reconstruction | bit string.  A chunk's bit
-        // string is almost always smaller than its frames; the worst case (icsp_bitstream_bound, 7x) is only allocated if the
-        // packer reports that it does not fit
+        const int cmax = std::min(chunk, n);
+        w->rc = icsp_create(&w->ctx, &params, w->device, cmax);
+        if (!w->rc) w->rc = icsp_prepare(w->ctx);
+        if (w->rc) w->err = std::string(icsp_strerror(w->rc)) + ": " + (w->ctx ? icsp_last_error(w->ctx) : "");
+        maps_settled.wait();
+        // pinned staging (each allocation costs milliseconds) only for whichever side is not mapped
         const size_t cbytes = (fsz * cmax + 255) & ~(size_t)255;
-        s->in = (uint8_t*)icsp_host_alloc(cbytes * (opt.hostpack ? 2 : 3));
-        if (!s->in) { s->rc = ICSP_ERR_MEM_ALLOC; s->err = "pinned host memory"; return; }
-        s->recon = s->in + cbytes;
-        if (!opt.hostpack) { s->body_cap = cbytes; s->body = s->recon + cbytes; s->body_own = false; }
-        s->t_setup = now() - t0;
-        for (int c0 = 0; c0 < s->count; c0 += cmax) {
-            const int cn = std::min(cmax, s->count - c0);
-            const size_t f = (size_t)s->first + c0, bytes = fsz * cn;
+        uint8_t* stage_in = nullptr; uint8_t* stage_out = nullptr;
+        const size_t nstage = (in_map ? 0 : 1) + (out_map ? 0 : 1);
+        if (!w->rc && nstage) {
+            w->stage = (uint8_t*)icsp_host_alloc(cbytes * nstage);
+            if (!w->stage) { w->rc = ICSP_ERR_MEM_ALLOC; w->err = "pinned host memory"; }
+            stage_in = in_map ? nullptr : w->stage;
+            stage_out = out_map ? nullptr : w->stage + (in_map ? 0 : cbytes);
+        }
+        // a chunk's bit string that cannot go straight into the .bin mapping comes back through a pinned buffer: almost
+        // always far smaller than the frames; the worst case (icsp_bitstream_bound, 7x) only if the packer says so
+        auto need_body = [&](size_t want) {
+            if (w->body_cap >= want) return true;
+            icsp_host_free(w->body);
+            w->body = (uint8_t*)icsp_host_alloc(want);
+            w->body_cap = w->body ? want : 0;
+            return w->body != nullptr;
+        };
+        if (!w->rc && !opt.hostpack && !bin_pinned && !need_body(std::max<size_t>(cbytes / 2, (size_t)1 << 20))) { w->rc = ICSP_ERR_MEM_ALLOC; w->err = "pinned host memory"; }
+        // the first transfer into a newly pinned mapping costs its hipMemcpyAsync call about 6 ms: spend it now, on the string of
+        // icsp_prepare's black GOP, and clear those bytes again (the image has to start out zeroed)
+        if (!w->rc && !opt.hostpack && bin_pinned) {
+            uint64_t b = 0;
+            if (icsp_pack_count(w->ctx, 0, std::min(L, cmax), &b) == ICSP_OK && 14 + (size_t)(b / 8) + 2 <= bin_est &&
+                icsp_pack_into(w->ctx, 0, std::min(L, cmax), 0, bin_map + 14, bin_est - 14) == ICSP_OK)
+                memset(bin_map + 14, 0, (size_t)(b / 8) + 1);
+        }
+        w->t_setup = now() - t0;
+        {   // every worker arrives here, failed or not; the last arrival ends "init"
+            std::unique_lock<std::mutex> l(ready.m);
+            if (++ready.waiting == ready.total) { ready.t_last = now(); ready.cv.notify_all(); }
+            else ready.cv.wait(l, [&] { return ready.waiting == ready.total; });
+        }
+        auto fail = [&](int rc, const char* what) {
+            w->rc = rc; w->err = std::string(icsp_strerror(rc)) + ": " + (what ? what : icsp_last_error(w->ctx));
+            { std::lock_guard<std::mutex> l(cursor.m); cursor.failed = true; }
+            cursor.cv.notify_all();
+        };
+        if (w->rc) { fail(w->rc, w->err.c_str()); return; }
+        for (int c; (c = next_chunk.fetch_add(1)) < nchunks;) {
+            Chunk& ch = chunks[c];
+            const int cn = ch.count;
+            const size_t f = (size_t)ch.first, bytes = fsz * cn;
+            const uint8_t* src = in_map ? in_map + f * fsz : stage_in;
+            uint8_t* rec = out_map ? out_map + f * fsz : stage_out;
             t0 = now();
-            if (!pread_all(fd_in, s->in, bytes, (off_t)(f * fsz))) { s->rc = ICSP_ERR_RANGE; s->err = "short read"; return; }
-            s->t_read += now() - t0; t0 = now();
+            if (!in_map && !pread_all(fd_in, stage_in, bytes, (off_t)(f * fsz))) { fail(ICSP_ERR_RANGE, "short read"); return; }
+            w->t_read += now() - t0;
+            int rc;
             if (opt.hostpack) {
-                s->rc = icsp_encode_gop(s->ctx, s->in, cn, levels.data() + f * nmb * 384, acflag.data() + f * nmb * 6,
-                                        mpm.data() + f * nmb * 4, mvd.data() + f * nmb * 2, s->recon);
+                t0 = now();
+                rc = icsp_encode_gop(w->ctx, src, cn, levels.data() + f * nmb * 384, acflag.data() + f * nmb * 6,
+                                     mpm.data() + f * nmb * 4, mvd.data() + f * nmb * 2, rec);
+                w->t_enc += now() - t0;
+                if (rc) { fail(rc, nullptr); return; }
             } else {
+                t0 = now();
+                rc = icsp_upload(w->ctx, src, 0, cn);
+                w->t_up += now() - t0; t0 = now();
+                if (!rc) rc = icsp_encode_resident(w->ctx, 0, cn);
+                w->t_enc += now() - t0; t0 = now();
                 uint64_t bits = 0;
-                s->rc = icsp_upload(s->ctx, s->in, 0, cn);
-                if (!s->rc) s->rc = icsp_encode_resident(s->ctx, 0, cn);
-                if (!s->rc) s->rc = icsp_pack_bits(s->ctx, 0, cn, s->body, s->body_cap, &bits);
-                if (s->rc == ICSP_ERR_RANGE) {
-                    s->body_own = true;
-                    s->body_cap = icsp_bitstream_bound(&params, cmax);
-                    s->body = (uint8_t*)icsp_host_alloc(s->body_cap);
-                    s->rc = s->body ? icsp_pack_bits(s->ctx, 0, cn, s->body, s->body_cap, &bits) : ICSP_ERR_MEM_ALLOC;
+                if (!rc) rc = icsp_pack_count(w->ctx, 0, cn, &bits);
+                w->t_count += now() - t0; t0 = now();
+                if (rc) { fail(rc, nullptr); return; }
+                {   // my turn: every earlier chunk has reported its length
+                    std::unique_lock<std::mutex> l(cursor.m);
+                    cursor.cv.wait(l, [&] { return cursor.turn == c || cursor.failed; });
+                    if (cursor.failed) return;
+                    ch.at = cursor.bits; ch.bits = bits;
+                    cursor.bits += bits; cursor.turn++;
                 }
-                if (!s->rc) s->rc = icsp_download(s->ctx, 0, cn, nullptr, nullptr, nullptr, nullptr, s->recon);
-                if (!s->rc) {
-                    s->pieces.emplace_back();
-                    s->pieces.back().bits = bits;
-                    s->pieces.back().bytes.assign(s->body, s->body + (size_t)((bits + 7) / 8));
-                    s->bits += bits;
+                cursor.cv.notify_all();
+                w->t_turn += now() - t0; t0 = now();
+                const size_t end_byte = 14 + (size_t)((ch.at + bits + 7) / 8);
+                ch.direct = bin_pinned && end_byte <= bin_est;
+                if (ch.direct) rc = icsp_pack_into(w->ctx, 0, cn, ch.at, bin_map + 14, bin_est - 14);
+                else {
+                    const size_t nb = (size_t)((bits + 7) / 8);
+                    if (!need_body(std::max<size_t>(nb, (size_t)1 << 20))) rc = ICSP_ERR_MEM_ALLOC;
+                    else rc = icsp_pack_bits(w->ctx, 0, cn, w->body, w->body_cap, &bits);
+                    if (!rc) ch.bytes.assign(w->body, w->body + nb);
                 }
+                w->t_pack += now() - t0; t0 = now();
+                if (!rc) rc = icsp_download(w->ctx, 0, cn, nullptr, nullptr, nullptr, nullptr, rec);
+                w->t_down += now() - t0;
+                if (rc) { fail(rc, nullptr); return; }
             }
-            if (s->rc) { s->err = std::string(icsp_strerror(s->rc)) + ": " + icsp_last_error(s->ctx); return; }
-            s->t_gpu += now() - t0; t0 = now();
-            if (fd_rec >= 0) pwrite_all(fd_rec, s->recon, bytes, (off_t)(f * fsz));
-            s->t_write += now() - t0;
+            t0 = now();
+            if (!out_map && fd_rec >= 0) pwrite_all(fd_rec, stage_out, bytes, (off_t)(f * fsz));
+            w->t_write += now() - t0;
+            w->chunks++;
         }
     };
     {
         std::vector<std::thread> th;
-        for (int d = 1; d < nshard; d++) th.emplace_back(work, &shards[d]);
-        work(&shards[0]);
+        for (int d = 1; d < nworker; d++) th.emplace_back(work, &workers[d]);
+        work(&workers[0]);
         for (auto& t : th) t.join();
     }
-    for (auto& s : shards)
-        if (s.rc) { printf("[ERROR] GPU %d: %s\n", s.device, s.err.c_str()); exit(-1); }
+    helper.join();
+    for (auto& w : workers)
+        if (w.rc) { printf("[ERROR] GPU %d: %s\n", w.device, w.err.c_str()); exit(-1); }
+    const double t_init_done = ready.t_last;
     const double t_encoded = now();
 
     for (int f = 0; f < n; f++)                                            // print_frame_end_message (ENC:44-48)
         printf("Encoding FRAME_%03d(%c) done!\n", f, (opt.intra_period == 0 || f % opt.intra_period == 0) ? 'I' : 'P');
 
-    // makebitstream (ENC:4849-4900)
+    // makebitstream (ENC:4849-4900), the rest of it: header, the strings that did not go direct (cut into 1 MB runs and
+    // placed by several threads), the reference's final byte; the image is the .bin mapping when there is one
     size_t nbytes = 0;
-    std::vector<uint8_t> bs;
     int rc;
-    if (opt.hostpack) {
-        bs.resize(icsp_bitstream_bound(&params, n) + 2);
-        rc = icsp_write_bitstream(&params, n, levels.data(), acflag.data(), mpm.data(), mvd.data(), bs.data(), bs.size(), &nbytes);
-    } else {
-        uint64_t total = 0;
-        std::vector<uint64_t> at(nshard);
-        for (int d = 0; d < nshard; d++) { at[d] = total; total += shards[d].bits; }
-        bs.resize(14 + (size_t)(total / 8) + 3);
-        rc = icsp_bitstream_begin(&params, total, bs.data(), bs.size(), &nbytes);
-        if (!rc) {
-            std::vector<std::thread> th;
-            auto place = [&](int d) {
-                uint64_t o = at[d];
-                for (auto& pc : shards[d].pieces) {
-                    if (int r = icsp_bitstream_place(bs.data(), bs.size(), o, pc.bytes.data(), pc.bits)) shards[d].rc = r;
-                    o += pc.bits;
-                }
-            };
-            for (int d = 1; d < nshard; d++) th.emplace_back(place, d);
-            place(0);
-            for (auto& t : th) t.join();
-            for (auto& s : shards) if (s.rc) rc = s.rc;
+    const uint64_t total = cursor.bits;
+    auto finish = [&](uint8_t* img, size_t cap, bool zeroed) -> int {
+        if (opt.hostpack) return icsp_write_bitstream(&params, n, levels.data(), acflag.data(), mpm.data(), mvd.data(), img, cap, &nbytes);
+        int r = zeroed ? icsp_bitstream_header(&params, total, img, cap, &nbytes) : icsp_bitstream_begin(&params, total, img, cap, &nbytes);
+        if (r) return r;
+        struct Run { uint64_t at; const uint8_t* p; uint64_t bits; };
+        std::vector<Run> runs;
+        const size_t kRun = (size_t)1 << 20;
+        for (auto& ch : chunks) {
+            if (ch.direct) continue;
+            const size_t nb = (size_t)((ch.bits + 7) / 8);
+            for (size_t o = 0; o < nb; o += kRun)
+                runs.push_back({ ch.at + 8 * (uint64_t)o, ch.bytes.data() + o, std::min<uint64_t>(8 * (uint64_t)kRun, ch.bits - 8 * (uint64_t)o) });
         }
-        if (!rc) rc = icsp_bitstream_end(bs.data(), total);
+        if (!runs.empty()) {
+            const int nt = (int)std::min<size_t>({ runs.size(), (size_t)16, (size_t)std::max(1u, std::thread::hardware_concurrency()) });
+            std::atomic<size_t> next(0);
+            std::atomic<int> bad(0);
+            auto place = [&] {
+                for (size_t k; (k = next.fetch_add(1)) < runs.size();)
+                    if (int e = icsp_bitstream_place(img, cap, runs[k].at, runs[k].p, runs[k].bits)) bad = e;
+            };
+            std::vector<std::thread> th;
+            for (int t = 1; t < nt; t++) th.emplace_back(place);
+            place();
+            for (auto& t : th) t.join();
+            if (bad.load()) return bad.load();
+        }
+        return icsp_bitstream_end(img, total);
+    };
+    double t_fin = 0, t_trunc = 0;
+    if (bin_map) {
+        double t0 = now();
+        rc = finish(bin_map, bin_cap, true);                      // a fresh file's pages are zero
+        t_fin = now() - t0; t0 = now();
+        if (bin_pinned) icsp_host_unregister(bin_map);
+        if (!rc && ftruncate(fd_bin, (off_t)nbytes) != 0) rc = ICSP_ERR_RANGE;
+        t_trunc = now() - t0;
+    } else {
+        std::vector<uint8_t> bs(opt.hostpack ? bin_cap : 14 + (size_t)(total / 8) + 3);
+        rc = finish(bs.data(), bs.size(), false);
+        if (!rc && (ftruncate(fd_bin, 0) != 0 || !pwrite_all(fd_bin, bs.data(), nbytes, 0))) rc = ICSP_ERR_RANGE;
     }
     if (rc) { printf("[ERROR] %s in makebitstream\n", icsp_strerror(rc)); exit(-1); }
-    char name[512];
-    snprintf(name, sizeof(name), "%s_compCIF_%d_%d_%d.bin", prefix.c_str(), opt.qp_dc, opt.qp_ac, opt.intra_period);
-    FILE* out = fopen(name, "wb");
-    if (!out) { printf("fail to open compCIF.bin\n"); exit(-1); }
-    fwrite(bs.data(), nbytes, 1, out);
-    fclose(out);
+    close(fd_bin);
     if (fd_rec < 0) printf("fail to save yuv\n");
     else close(fd_rec);
     close(fd_in);
     const double t_files = now();
     if (opt.stats) {
-        double su = 0, rd = 0, gp = 0, wr = 0;
-        for (auto& s : shards) { su = std::max(su, s.t_setup); rd = std::max(rd, s.t_read); gp = std::max(gp, s.t_gpu); wr = std::max(wr, s.t_write); }
-        printf("[icsp_enc]{\"frames\": %d, \"shards\": %d, \"devices\": %d, \"chunk_frames\": %d, \"init_s\": %.4f, \"encode_s\": %.4f, "
-               "\"bitstream_and_files_s\": %.4f, \"max_shard_setup_s\": %.4f, \"max_shard_read_s\": %.4f, \"max_shard_gpu_s\": %.4f, "
-               "\"max_shard_write_s\": %.4f, \"e2e_fps_excl_init\": %.1f, \"e2e_fps_incl_init\": %.1f}\n",
-               n, nshard, std::min(ndev, nshard), chunk, t_init_done - t_start, t_encoded - t_init_done, t_files - t_encoded, su, rd, gp, wr,
-               n / (t_files - t_init_done), n / (t_files - t_start));
+        int ndirect = 0;
+        for (auto& ch : chunks) ndirect += ch.direct ? 1 : 0;
+        double su = 0;
+        for (auto& w : workers) su = std::max(su, w.t_setup);
+        const Worker& w0 = workers[0];
+        printf("[icsp_enc]{\"frames\": %d, \"workers\": %d, \"devices\": %d, \"chunk_frames\": %d, \"chunks\": %d, \"chunks_packed_into_bin_mapping\": %d, "
+               "\"input_mapped\": %s, \"output_mapped\": %s, \"bin_mapped\": %s, "
+               "\"init_s\": %.4f, \"encode_s\": %.4f, \"bitstream_and_files_s\": %.4f, \"map_files_s\": %.4f, \"pin_mappings_s\": %.4f, "
+               "\"max_worker_setup_s\": %.4f, \"worker0\": {\"chunks\": %d, \"read_s\": %.4f, \"upload_s\": %.4f, \"encode_call_s\": %.4f, \"pack_count_s\": %.4f, "
+               "\"turn_wait_s\": %.4f, \"pack_s\": %.4f, \"download_s\": %.4f, \"write_s\": %.4f}, "
+               "\"bin_finish_s\": %.4f, \"bin_truncate_s\": %.4f, \"bin_bytes\": %zu, \"e2e_fps_excl_init\": %.1f, \"e2e_fps_incl_init\": %.1f}\n",
+               n, nworker, std::min(ndev, nworker), chunk, nchunks, ndirect, in_map ? "true" : "false", out_map ? "true" : "false", bin_pinned ? "true" : "false",
+               t_init_done - t_start, t_encoded - t_init_done, t_files - t_encoded, t_map, t_pin, su,
+               w0.chunks, w0.t_read, w0.t_up, w0.t_enc, w0.t_count, w0.t_turn, w0.t_pack, w0.t_down, w0.t_write,
+               t_fin, t_trunc, nbytes, n / (t_files - t_init_done), n / (t_files - t_start));
     }
     // contexts and pinned buffers go last: tearing the runtime down is not part of producing the files
-    for (auto& s : shards) { icsp_host_free(s.in); if (s.body_own) icsp_host_free(s.body); icsp_destroy(s.ctx); }
+    // (the mappings stay pinned until the process ends: unpinning and unmapping them is not part of producing the files either)
+    for (auto& w : workers) { icsp_host_free(w.stage); icsp_host_free(w.body); icsp_destroy(w.ctx); }
     return 0;
 }

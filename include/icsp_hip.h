@@ -131,6 +131,19 @@ int icsp_write_bitstream(const icsp_params_t* params, int n,
  * bit count to *nbits.  Only the bits cross PCIe instead of levels/flags/vectors (about 1/30 of the bytes at QP 16).
  * cap >= icsp_bitstream_bound() - 14 always suffices; ICSP_ERR_RANGE if the body does not fit cap. */
 int icsp_pack_bits(icsp_ctx_t* ctx, int first_frame, int n, uint8_t* body, size_t cap, uint64_t* nbits);
+/* The same in two steps, for hosts that build ONE image out of several batches without touching the bits on the CPU
+ * (icsp_enc): icsp_pack_count runs the length and prefix-sum kernels and returns the bit count of the range; once the host
+ * knows where the string starts in the body (at_bit = sum of the counts before it), icsp_pack_into packs it on the device
+ * at that bit phase and copies its whole bytes to body_image + at_bit/8 (by DMA when the image is pinned memory, e.g. a
+ * registered mapping of the .bin); the first and last byte, which neighbouring strings may share, are OR-ed in
+ * atomically, so the image must start out zeroed and concurrent calls from several contexts are safe.  body_image is the
+ * body, i.e. the .bin image + 14; cap its capacity in bytes.  Both synchronise.  icsp_pack_into must follow an
+ * icsp_pack_count of the same range (ICSP_ERR_RANGE otherwise, or when the string does not fit cap). */
+int icsp_pack_count(icsp_ctx_t* ctx, int first_frame, int n, uint64_t* nbits);
+int icsp_pack_into(icsp_ctx_t* ctx, int first_frame, int n, uint64_t at_bit, uint8_t* body_image, size_t cap);
+/* Creates now what an encode / pack would create on first use (GOP-group streams, packer buffers, first launches) by
+ * encoding and packing up to two GOPs of black frames in slots [0, ...): for hosts that time or pipeline their batches. */
+int icsp_prepare(icsp_ctx_t* ctx);
 /* Host: header + the pieces (each an MSB-first bit string of piece_bits[i] bits, e.g. one per GPU shard, in frame
  * order) concatenated bit-wise + the reference's final byte (its bits right-aligned, ENC:4956) -> the .bin image,
  * identical to icsp_write_bitstream on the same frames.  *out_bytes = 14 + total_bits/8 + 1. */
@@ -141,6 +154,9 @@ int icsp_bitstream_assemble(const icsp_params_t* params, int npieces, const uint
  * and writes the header, place puts one piece at its bit offset in the body (thread-safe for disjoint bit ranges), end
  * right-aligns the final partial byte. */
 int icsp_bitstream_begin(const icsp_params_t* params, uint64_t total_bits, uint8_t* image, size_t cap, size_t* out_bytes);
+/* begin without the zeroing: only the 14 header bytes (for an image that is zero already, e.g. a fresh file mapping that
+ * icsp_pack_into has filled meanwhile); *out_bytes as above. */
+int icsp_bitstream_header(const icsp_params_t* params, uint64_t total_bits, uint8_t* image, size_t cap, size_t* out_bytes);
 int icsp_bitstream_place(uint8_t* image, size_t cap, uint64_t bit_offset, const uint8_t* piece, uint64_t piece_bits);
 int icsp_bitstream_end(uint8_t* image, uint64_t total_bits);
 
@@ -149,6 +165,13 @@ int icsp_bitstream_end(uint8_t* image, uint64_t total_bits);
  *      runtime.  NULL when there is no device or no memory. ---- */
 void* icsp_host_alloc(size_t bytes);
 void icsp_host_free(void* p);
+/* Pin a range the caller already owns (hipHostRegister) -- in particular a mapping of the input file (read_only != 0: mapped
+ * without write permission) or of the output file (MAP_SHARED, pages populated): icsp_upload then reads the frames and
+ * icsp_download writes the reconstruction by DMA from/into the page cache, with no staging copy on the host (the reference's
+ * YCbCrLoad fread, ENC:247-283, and checkResultFrames fwrite, ENC:6376-6413, become the transfers themselves).  The range is
+ * usable from every device.  ICSP_ERR_HIP when the runtime refuses the range (callers fall back to staging buffers). */
+int icsp_host_register(void* p, size_t bytes, int read_only);
+int icsp_host_unregister(void* p);
 
 /* ---- decoder side: DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp ---- */
 /* Host: readHeader (DEC:14-37).  intra_period is the header field as stored: 1 (or 0) = every frame intra (DEC.h:293). */

@@ -14,7 +14,7 @@ ENC = os.path.join(ROOT, "icspcodec_amd", "icsp_enc")
 
 
 def run(args, cwd):
-    return subprocess.run([ENC] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    return subprocess.run([ENC] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
 
 
 def test_option_errors_match_reference_messages_and_exit_code(tmp_path):
@@ -36,7 +36,10 @@ def test_option_errors_match_reference_messages_and_exit_code(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("period,extra", [(6, []), (0, []), (1, []), (6, ["--EnMultiThread", "1"]), (6, ["--hostpack"]),
-                                          (0, ["--hostpack"])])
+                                          (0, ["--hostpack"]), (6, ["--staged"]), (0, ["--staged", "--chunk", "5"]),
+                                          (6, ["--chunk", "6", "--streams", "2"]), (6, ["--staged", "--hostpack", "--chunk", "1"]),
+                                          (6, ["--chunk", "6", "--streams", "2", "--binest", "200000"]),
+                                          (0, ["--chunk", "3", "--streams", "3", "--binest", "4096"])])
 def test_cli_outputs_equal_reference_files(tmp_path, golden_dir, period, extra):
     n, qp = 12, 16
     clip = clipgen.synth_clip("foremanlike", n)
@@ -57,7 +60,8 @@ DEC = os.path.join(ROOT, "icspcodec_amd", "icsp_dec")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [["--gpus", "2"], ["--gpus", "3", "--hostpack"], ["--EnMultiThread", "2"], ["--EnMultiThread", "4"]])
+@pytest.mark.parametrize("extra", [["--gpus", "2"], ["--gpus", "3", "--hostpack"], ["--EnMultiThread", "2"], ["--EnMultiThread", "4"],
+                                   ["--EnMultiThread", "2", "--staged"]])
 def test_cli_multi_shard_path_on_one_gpu(tmp_path, golden_dir, extra):
     """--gpus N / --EnMultiThread N with more shards than devices (shards share devices round-robin): closed-GOP shards in
     their own contexts and threads, one bit-string piece per shard concatenated bit-wise on the host -> the same files as
@@ -67,7 +71,7 @@ def test_cli_multi_shard_path_on_one_gpu(tmp_path, golden_dir, extra):
     fn = clipgen.file_name("foremanlike", n)
     clip.tofile(tmp_path / fn)
     r = subprocess.run([ENC, "-i", fn, "-n", str(n), "-q", str(qp), "--intraPeriod", str(period)] + extra, cwd=tmp_path,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode == 0, r.stdout
     streams = json.load(open(os.path.join(golden_dir, "streams.json")))
     ref = [s for s in streams if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", n, qp, period) and "bin_sha256" in s][0]

@@ -287,6 +287,44 @@ def test_device_bit_packer_equals_host_writer(name, n, q, period, w, h):
     enc.close()
 
 
+@pytest.mark.parametrize("name,n,q,period,cuts", [("foremanlike", 12, 16, 6, [6]), ("staticlike", 9, 16, 3, [3, 6]),
+                                                   ("foremanlike", 8, 1, 0, [1, 2, 3, 5]), ("stefanlike", 20, 8, 10, [10])])
+def test_pack_into_builds_the_image_in_place(name, n, q, period, cuts):
+    """icsp_pack_count + icsp_pack_into from two contexts, batch by batch, straight into ONE zero-initialised image at the
+    running bit offset (odd byte and bit phases, strings shorter than the 64-byte alignment window included) + header +
+    final byte == icsp_write_bitstream; and a repeated icsp_prepare in between does not disturb anything."""
+    clip = clipgen.synth_clip(name, n)
+    ref = capi.Encoder(W, H, q, q, period, max_frames=n)
+    o = ref.encode(clip)
+    want = capi.write_bitstream(W, H, q, q, period, o["levels"], o["acflag"], o["mpm"], o["mvd"])
+    ref.close()
+    bounds = [0] + cuts + [n]
+    cmax = max(b - a for a, b in zip(bounds, bounds[1:]))
+    encs = [capi.Encoder(W, H, q, q, period, max_frames=cmax) for _ in range(2)]
+    for e in encs:
+        e.prepare()
+    for offset in (0, 3):                                # image at an odd address as well (the alignment logic follows it)
+        buf = np.zeros(len(want) + 64 + offset, np.uint8)
+        image = buf[offset:]
+        at = 0
+        for k, (a, b) in enumerate(zip(bounds, bounds[1:])):
+            e = encs[k % 2]
+            e.upload(clip[a:b], 0)
+            e.encode_resident(0, b - a)
+            bits = e.pack_count(0, b - a)
+            e.pack_into(0, b - a, at, image[14:])
+            at += bits
+            if k == 0:
+                e.prepare()
+        got = capi.finish_image(W, H, q, q, period, image, at)
+        assert len(got) == len(want)
+        assert got == want
+    with pytest.raises(RuntimeError):                    # pack_into without a count of that range
+        encs[0].pack_into(0, 1, 0, np.zeros(1 << 20, np.uint8))
+    for e in encs:
+        e.close()
+
+
 def test_device_bit_packer_full_baseline_hash(golden_dir):
     """BASELINE configs[2] (stefanlike 300 f, --intraPeriod 10, QP 8): device-packed .bin SHA-256 == the reference CLI's."""
     streams = json.load(open(os.path.join(golden_dir, "streams.json")))
