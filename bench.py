@@ -480,6 +480,15 @@ def main():
             roof["fp64_valu_frac"] = round(ops * 64 / (kern_ms * 1e-3) / 1e9 / FP64_VALU_PEAK_GOPS, 4)
             roof["fp64_valu_peak_Gops"] = round(FP64_VALU_PEAK_GOPS, 1)
             roof["fp64_valu_source"] = pmc.get("source")
+        # every vector instruction of a wave holds its SIMD's issue port for >= 4 cycles (measured: 4.0-4.5; conversions to and
+        # from f64 7.2; tools/probe_issue.hip), so wave-instructions / (SIMDs x clock / 4) is the share of the chip's vector
+        # issue slots this launch fills.  Chip-wide figure; the 44 of 256 CUs that carry two of the 300 frames, and decide
+        # the launch time, run at about 2 x 256/300 x this / (1 - idle share) -- DESIGN.md section 5.
+        vi = pmc.get("valu_insts_per_launch")
+        if vi:
+            peak = 256 * 4 * 2.4e9 / 4                        # 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles at 2.4 GHz
+            roof["valu_issue_frac"] = round(vi / (kern_ms * 1e-3) / peak, 4)
+            roof["valu_issue_peak_Ginst"] = round(peak / 1e9, 1)
     line = {
         "metric": "CIF encode fps, resident encode loop (all-intra QP=16; IPPP and the 8-GPU workloads alongside)", "value": round(fps, 1),
         "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
