@@ -1015,21 +1015,19 @@ int icsp_prepare(icsp_ctx_t* ctx)
         for (int k = 1; k < ctx->p_groups; k++) HIPCHK(hipMemsetAsync(ctx->b.me_done, 0, sizeof(int), ctx->pstream[k]));    // first use of the queue
         for (int k = 1; k < ctx->p_groups; k++) HIPCHK(hipStreamSynchronize(ctx->pstream[k]));
     }
-    {   // the first DMA of a process in each direction costs about 6 ms inside the hipMemcpyAsync call, whatever its size
-        // (a transfer queue is set up); the device-to-host one only counts towards memory pinned by hipHostRegister
+    {   // a stream's first host-to-device DMA costs about 6 ms inside the hipMemcpyAsync call, whatever its size (a transfer
+        // queue is set up).  (Pinned by hipHostMalloc rather than registered and unregistered on the spot: contexts are
+        // prepared concurrently, and pinning calls racing with other threads' transfers are best avoided.)
         const size_t nb = std::min<size_t>((size_t)1 << 20, (size_t)ctx->max_frames * ctx->g.fsz);
-        void* h = aligned_alloc(4096, (nb + 4095) & ~(size_t)4095);
-        if (h) {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, nb, hipHostMallocDefault) == hipSuccess) {
             memset(h, 0, nb);
-            if (hipHostRegister(h, nb, hipHostRegisterPortable) == hipSuccess) {
-                (void)hipMemcpyAsync(ctx->d_frames, h, nb, hipMemcpyHostToDevice, ctx->stream);
-                (void)hipStreamSynchronize(ctx->stream);
-                (void)hipMemcpyAsync(h, ctx->d_frames, nb, hipMemcpyDeviceToHost, ctx->stream);
-                (void)hipStreamSynchronize(ctx->stream);
-                (void)hipHostUnregister(h);
-            } else (void)hipGetLastError();
-            free(h);
-        }
+            (void)hipMemcpyAsync(ctx->d_frames, h, nb, hipMemcpyHostToDevice, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpyAsync(h, ctx->d_frames, nb, hipMemcpyDeviceToHost, ctx->stream);
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipHostFree(h);
+        } else (void)hipGetLastError();
     }
     HIPCHK(hipMemsetAsync(ctx->d_frames, 0, (size_t)n * ctx->g.fsz, ctx->stream));
     ctx->st_ahead = true;
