@@ -176,37 +176,62 @@ int icsp_bitstream_assemble(const icsp_params_t* p, int npieces, const uint8_t* 
 // ---- the inverse: readHeader (DEC:14-37) and readBlockData (DEC:38-405) of the reference DECODER
 // (DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp)
 namespace {
+// Reads through a 64-bit window: one unaligned load gives at least 57 valid bits at the cursor, enough for any code of the
+// table (at most 3 + 7 + 1 + 11 = 22 bits), and a run of zero values ("00" each) is counted with one count-leading-zeros.
+// Semantics of the bit-serial reader it replaces: MSB first (DEC:64-70), zeros past the end, `over` once a bit at or
+// beyond nbits has been read.
 struct BitReader {
     const uint8_t* p; uint64_t nbits, at; bool over;
-    inline uint32_t bit()                                              // MSB first (DEC:64-70); zeros past the end
+    inline uint64_t peek() const                                       // bits at, at+1, ... from the top; >= 57 valid, zeros past the end
     {
-        if (at >= nbits) { over = true; at++; return 0; }
-        const uint32_t v = (p[at >> 3] >> (7 - (at & 7))) & 1u;
-        at++;
-        return v;
+        const uint64_t byte = at >> 3, nbytes = nbits >> 3;
+        uint64_t w = 0;
+        if (byte + 8 <= nbytes) { memcpy(&w, p + byte, 8); w = __builtin_bswap64(w); }
+        else for (int k = 0; k < 8; k++) if (byte + k < nbytes) w |= (uint64_t)p[byte + k] << (56 - 8 * k);
+        return w << (at & 7);
     }
-    inline uint32_t bits(int n) { uint32_t v = 0; for (int i = 0; i < n; i++) v = (v << 1) | bit(); return v; }
-    // one value of the DC / AC / MV code (DCientropy DEC:407-608, ACientropy DEC:810-1021, MVientropy DEC:2274-2653)
-    inline int value()
+    inline void skip(int n) { at += (uint64_t)n; if (at > nbits) over = true; }
+    inline uint32_t bit() { const uint32_t v = (uint32_t)(peek() >> 63); skip(1); return v; }
+    // one value of the DC / AC / MV code (DCientropy DEC:407-608, ACientropy DEC:810-1021, MVientropy DEC:2274-2653):
+    // "00" = 0; else a 3-bit category: 010 -> e = 0, 011..110 -> e = 1..4, 111 -> e = 5 + the ones that follow (at most six;
+    // the bit that ends them -- or, after six, one more bit whatever it is -- is consumed); then the sign, then e bits
+    inline int value_from(uint64_t w, int& len)
     {
-        uint32_t c = bits(2);
-        if (c == 0) return 0;
-        c = (c << 1) | bit();
-        int e;
-        if (c == 2) e = 0;
-        else if (c < 7) e = (int)c - 2;
-        else { e = 5; while (e < 11 && bit() == 1) e++; if (e == 11) bit(); }
-        const uint32_t s = bit();
-        const int a = (1 << e) + (int)bits(e);
+        const uint32_t c = (uint32_t)(w >> 61);
+        if (c < 2) { len = 2; return 0; }
+        int e, pre;
+        if (c == 2) { e = 0; pre = 3; }
+        else if (c < 7) { e = (int)c - 2; pre = 3; }
+        else {
+            const uint32_t six = (uint32_t)(w >> 55) & 63u;            // the six bits after the category
+            const uint32_t inv = ~six & 63u;
+            const int ones = inv ? __builtin_clz(inv) - 26 : 6;         // leading ones of the six
+            e = 5 + ones; pre = 3 + ones + 1;
+        }
+        const uint32_t s = (uint32_t)(w >> (63 - pre)) & 1u;
+        const uint32_t low = e ? (uint32_t)((w << (pre + 1)) >> (64 - e)) : 0u;
+        len = pre + 1 + e;
+        const int a = (1 << e) + (int)low;
         return s ? a : -a;
     }
+    inline int value() { int len; const int v = value_from(peek(), len); skip(len); return v; }
     inline void block(int16_t* lv, uint8_t* acflag)
     {
         lv[0] = (int16_t)value();
         const uint32_t ac = bit();
         *acflag = (uint8_t)ac;
-        if (ac) { at += 63; for (int i = 1; i < 64; i++) lv[i] = 0; }   // DEC:127-132
-        else for (int i = 1; i < 64; i++) lv[i] = (int16_t)value();
+        if (ac) { at += 63; for (int i = 1; i < 64; i++) lv[i] = 0; return; }    // DEC:127-132
+        for (int i = 1; i < 64;) {
+            const uint64_t w = peek();
+            // a run of zero values: every leading "00" pair of the window (28 pairs are always valid bits)
+            int z = w ? (__builtin_clzll(w) >> 1) : 28;
+            if (z > 28) z = 28;
+            if (z > 64 - i) z = 64 - i;
+            if (z) { for (int k = 0; k < z; k++) lv[i + k] = 0; i += z; skip(2 * z); continue; }
+            int len;
+            lv[i++] = (int16_t)value_from(w, len);
+            skip(len);
+        }
     }
 };
 } // namespace
