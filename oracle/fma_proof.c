@@ -42,15 +42,26 @@ static uint32_t rnd(void)
     return (uint32_t)(rng_state >> 33);
 }
 
-/* fuse1: fuse pass 1 (the claim); fuse2: also fuse pass 2 (must break) */
+/* fuse1: fuse pass 1 (the claim); fuse2: also fuse pass 2 (must break); fuse1 == 2: pass 1 FOLDED as the kernels do it
+ * since round 2 -- cos[u][7-x] == (-1)^u cos[u][x] holds literally in the table, so
+ *   tmp[v][u] = sum_{x<4} (err[v][x] +- err[v][7-x]) * cos[u][x]   (+ for even u, - for odd u),
+ * four terms instead of eight.  Nothing in pass 1 ever rounds (above; |err +- err'| <= 510 is one more bit, 38 in all), so
+ * both orders give the exact real value: the same double. */
 static void dct_variant(const int in[64], double out[64], int fuse1, int fuse2)
 {
     double tmp[8][8];
     for (int v = 0; v < 8; v++)
         for (int u = 0; u < 8; u++) {
-            double s = (double)in[v * 8] * g_cos[u][0];
-            for (int x = 1; x < 8; x++)
-                s = fuse1 ? fma((double)in[v * 8 + x], g_cos[u][x], s) : s + (double)in[v * 8 + x] * g_cos[u][x];
+            double s;
+            if (fuse1 == 2) {
+                const int sg = (u & 1) ? -1 : 1;
+                s = (double)(in[v * 8] + sg * in[v * 8 + 7]) * g_cos[u][0];
+                for (int x = 1; x < 4; x++) s = fma((double)(in[v * 8 + x] + sg * in[v * 8 + 7 - x]), g_cos[u][x], s);
+            } else {
+                s = (double)in[v * 8] * g_cos[u][0];
+                for (int x = 1; x < 8; x++)
+                    s = fuse1 ? fma((double)in[v * 8 + x], g_cos[u][x], s) : s + (double)in[v * 8 + x] * g_cos[u][x];
+            }
             tmp[v][u] = s;
         }
     for (int u = 0; u < 8; u++)
@@ -109,7 +120,10 @@ int main(int argc, char** argv)
             if (m > 16) m = 32 - m;
             dcos[u][x] = (m > 8) ? -dmag[16 - m] : dmag[m];
         }
-    long bad_f = 0, bad_fc = 0, bad_i = 0, bad_ic = 0, brk_f2 = 0, brk_i2 = 0, brk_dec = 0;
+    long bad_f = 0, bad_fc = 0, bad_i = 0, bad_ic = 0, brk_f2 = 0, brk_i2 = 0, brk_dec = 0, bad_fold = 0, bad_foldc = 0;
+    for (int u = 0; u < 8; u++)                       /* the symmetry the folded form rests on, literally */
+        for (int x = 0; x < 8; x++)
+            if (g_cos[u][7 - x] != ((u & 1) ? -g_cos[u][x] : g_cos[u][x])) { printf("table symmetry broken at [%d][%d]\n", u, x); return 1; }
     int in[64];
     double want[64], got[64], plain[64];
     for (long n = 0; n < nblk; n++) {
@@ -124,7 +138,9 @@ int main(int argc, char** argv)
             in[i] = v;
         }
         ref_dct_block(in, want);  dct_variant(in, got, 1, 0); bad_f += diff_bits(want, got) != 0;
+        dct_variant(in, got, 2, 0); bad_fold += diff_bits(want, got) != 0;
         ref_cdct_block(in, want); dct_variant(in, got, 1, 0); bad_fc += diff_bits(want, got) != 0;
+        dct_variant(in, got, 2, 0); bad_foldc += diff_bits(want, got) != 0;
         dct_variant(in, got, 1, 1); brk_f2 += diff_bits(want, got) != 0;
         /* inverse: dequantised coefficients level*q (+ DC predictor): |DC| up to 2*4080 + 1024, AC well inside +-2^15;
          * quantiser steps 1..255 make them multiples of q; sparse blocks as real streams have them */
@@ -146,10 +162,12 @@ int main(int argc, char** argv)
     printf("blocks %ld\n", nblk);
     printf("forward  pass-1 fused vs DCT_block   : %ld blocks differ (must be 0)\n", bad_f);
     printf("forward  pass-1 fused vs CDCT_block  : %ld blocks differ (must be 0)\n", bad_fc);
+    printf("forward  pass-1 folded vs DCT_block  : %ld blocks differ (must be 0)\n", bad_fold);
+    printf("forward  pass-1 folded vs CDCT_block : %ld blocks differ (must be 0)\n", bad_foldc);
     printf("inverse  pass-1 fused vs IDCT_block  : %ld blocks differ (must be 0)\n", bad_i);
     printf("inverse  pass-1 fused vs CIDCT_block : %ld blocks differ (must be 0)\n", bad_ic);
     printf("forward  pass-2 fused too            : %ld blocks differ (expected > 0: not bit-safe)\n", brk_f2);
     printf("inverse  pass-2 fused too            : %ld blocks differ (expected > 0: not bit-safe)\n", brk_i2);
     printf("decoder table, inverse pass-1 fused  : %ld blocks differ (expected > 0: not bit-safe)\n", brk_dec);
-    return (bad_f || bad_fc || bad_i || bad_ic) ? 1 : 0;
+    return (bad_f || bad_fc || bad_i || bad_ic || bad_fold || bad_foldc) ? 1 : 0;
 }
