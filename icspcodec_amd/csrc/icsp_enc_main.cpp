@@ -5,32 +5,34 @@
 //   parsing_command           ICSP_Codec_Encoder_source.cpp:94-165 (ENC)   -i -n -q --qpdc --qpac --intraPeriod --EnMultiThread -h --help
 //   YCbCrLoad                 ENC:247-283               planar I420 frames read from the input file
 //   single_thread_encoding    ENC:217-245               I/P decision per frame, "Encoding FRAME_%03d(%c) done!" lines
-//   multi_thread_encoding     ENC:179-213, ICSP_thread.cpp:39-77   closed-GOP job queue -> here: closed-GOP shards, one host thread each
+//   multi_thread_encoding     ENC:179-213, ICSP_thread.cpp:39-77   closed-GOP job queue -> here: a queue of closed-GOP chunks, N worker threads
 //   makebitstream             ENC:4849-4900             <prefix>_compCIF_<QDC>_<QAC>_<period>.bin
 //   checkResultFrames         ENC:6376-6421             test_yuv.yuv (reconstruction) in the working directory
 // What runs on the GPU is everything between loading the frames and writing the files, bit packing included
 // (include/icsp_hip.h).
 //
 // Streaming layout (load -> encode -> write of the reference, ENC:247-283 / 217-245 / 6376-6421, as a pipeline): the clip is
-// cut into shards of whole closed GOPs; every shard has a host thread and a context of its own and moves its frames through
-// the device in chunks of whole GOPs:  H2D -> kernels -> device bit packer -> D2H (bits + reconstruction).  The shards run
-// at different phases, so one's transfers overlap with another's kernels.
+// a queue of chunks of whole closed GOPs; workers -- a host thread and a context each -- take chunks in order and move them
+// through the device:  H2D -> kernels -> device bit packer -> D2H (bits + reconstruction).  The workers are at different
+// phases, so one's transfers overlap with another's kernels.
 //   * Mapped mode (default): the input file and test_yuv.yuv are mmap'ed and the mappings pinned (icsp_host_register), so the
 //     uploads read the page cache and the downloads write it by DMA -- the host copies nothing.  A helper thread maps the
 //     files and allocates the output's pages (MAP_POPULATE: the slowest host step, ~6 GB/s on tmpfs whatever the thread
 //     count) while the HIP runtime starts.
 //   * Staged mode (--staged, clips above the mapping cap, or when mapping / pinning is refused): pread -> pinned buffer ->
 //     device and device -> pinned buffer -> pwrite, per chunk.
-// Nothing is read or written twice and the output bytes do not depend on the mode, the chunk size or the number of shards.
+// Nothing is read or written twice and the output bytes do not depend on the mode, the chunk size or the number of workers.
 // The chunks' bit strings are placed into the (mmap'ed) .bin at their bit offsets by several threads (icsp_bitstream_place).
 //
 // Extensions use long options the reference rejects as unknown, so its own surface is unchanged:
 //   --hostpack      sequential bit writer on the host instead of the device packer (same bytes; for cross-checks)
-//   --gpus N        devices to shard over (default 1); --EnMultiThread N asks for N shards (the reference's N worker threads)
+//   --gpus N        devices to spread the workers over (default 1); --EnMultiThread N asks for N workers (the reference's N threads)
 //   --streams S     workers (contexts + host threads) per device when --EnMultiThread is not given (default: one per
 //                   chunk, at most 3)
 //   --chunk F       frames per chunk (rounded up to whole GOPs; default: 512 CIF frames' worth of macroblocks)
 //   --staged        staging buffers instead of pinned file mappings
+//   --binest B      bytes of the .bin mapping to populate and pin (default 30 % of the input + 1 MB); tests use it to push
+//                   chunks onto the host-placement path
 //   --width W --height H   frame size (the reference hard-codes 352x288, encoder_main.cpp:20)
 //   --stats         one more output line at the end: "[icsp_enc]{json}" with the wall-clock split (bench.py's e2e leg)
 // Deliberate differences: the thread-pool mode also writes the .bin (the reference commented that call out,
