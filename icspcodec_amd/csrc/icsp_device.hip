@@ -66,6 +66,16 @@ constexpr ZigZag make_zigzag()
     return z;
 }
 __constant__ ZigZag c_zz = make_zigzag();
+struct ZigZagCol { unsigned long long col[8]; };  // column u: the scan positions of (v = 0..7, u), one byte each, v = 0 lowest
+constexpr ZigZagCol make_zigzag_col()
+{
+    const ZigZag z = make_zigzag();
+    ZigZagCol c{};
+    for (int u = 0; u < 8; u++)
+        for (int v = 0; v < 8; v++) c.col[u] |= (unsigned long long)z.pos[v * 8 + u] << (8 * v);
+    return c;
+}
+__constant__ ZigZagCol c_zzcol = make_zigzag_col();
 
 // motion-search walk tables (filled by the host at icsp_create from its own simulation of ENC:2111-2125)
 struct MeTables {
