@@ -21,7 +21,7 @@ SYMBOLS = [
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
     "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
-    "icsp_bitstream_begin", "icsp_bitstream_header", "icsp_pack_count", "icsp_pack_into", "icsp_prepare", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free", "icsp_host_register", "icsp_host_unregister",
+    "icsp_bitstream_begin", "icsp_bitstream_header", "icsp_pack_count", "icsp_pack_into", "icsp_prepare", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free", "icsp_host_register", "icsp_host_unregister", "icsp_host_warm",
 ]
 KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode"]
 

@@ -1020,6 +1020,24 @@ int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap,
     return ICSP_OK;
 }
 
+// A stream's first large transfer into a newly pinned range can cost the hipMemcpyAsync call about 6 ms on this runtime
+// (transfers of less than a megabyte take another path and do not count).  This writes `bytes` ZERO bytes (at most 16 MB) from
+// the packer's scratch buffer to `pinned`, so a host can spend that during set-up on a range that must start out zeroed anyway.
+int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes)
+{
+    if (!ctx || !pinned) return ICSP_ERR_UNENOUGH_PARAM;
+    HIPCHK(hipSetDevice(ctx->device));
+    join_s2(ctx);
+    if (int rc = pack_alloc(ctx)) return rc;
+    const size_t nb = std::min({ bytes, ctx->pk_cap, (size_t)16 << 20 });
+    if (nb == 0) return ICSP_OK;
+    ctx->pk_first = -1;                                 // the scratch no longer holds a counted string
+    HIPCHK(hipMemsetAsync(ctx->pk.out, 0, nb, ctx->stream));
+    HIPCHK(hipMemcpyAsync(pinned, ctx->pk.out, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return ICSP_OK;
+}
+
 // Everything an encode or pack creates on first use (the GOP-group streams, the packer's buffers, the kernels' first
 // launches) is created now, by encoding one GOP of black frames and packing it -- a host that times or pipelines its
 // batches calls this while it sets up (icsp_enc).  The frame store's first GOP is overwritten.
@@ -1035,31 +1053,32 @@ int icsp_prepare(icsp_ctx_t* ctx)
         for (int k = 1; k < ctx->p_groups; k++) HIPCHK(hipMemsetAsync(ctx->b.me_done, 0, sizeof(int), ctx->pstream[k]));    // first use of the queue
         for (int k = 1; k < ctx->p_groups; k++) HIPCHK(hipStreamSynchronize(ctx->pstream[k]));
     }
-    {   // a stream's first host-to-device DMA costs about 6 ms inside the hipMemcpyAsync call, whatever its size (a transfer
-        // queue is set up).  (Pinned by hipHostMalloc rather than registered and unregistered on the spot: contexts are
-        // prepared concurrently, and pinning calls racing with other threads' transfers are best avoided.)
-        const size_t nb = std::min<size_t>((size_t)1 << 20, (size_t)ctx->max_frames * ctx->g.fsz);
-        void* h = nullptr;
-        if (hipHostMalloc(&h, nb, hipHostMallocDefault) == hipSuccess) {
-            memset(h, 0, nb);
-            (void)hipMemcpyAsync(ctx->d_frames, h, nb, hipMemcpyHostToDevice, ctx->stream);
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipMemcpyAsync(h, ctx->d_frames, nb, hipMemcpyDeviceToHost, ctx->stream);
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipHostFree(h);
-        } else (void)hipGetLastError();
-    }
+    // A stream's first host-to-device DMA costs about 6 ms inside the hipMemcpyAsync call, whatever its size (a transfer queue
+    // is set up), and so does its first LARGE device-to-host one that follows a kernel of ours (transfers below a megabyte, and
+    // ones behind the runtime's own fill kernels, take another path).  Both are spent here on a scratch buffer.  (Pinned by
+    // hipHostMalloc rather than registered and unregistered on the spot: contexts are prepared concurrently, and pinning
+    // calls racing with other threads' transfers are best avoided.)
+    const size_t nb = std::min<size_t>((size_t)4 << 20, (size_t)ctx->max_frames * ctx->g.fsz);
+    void* h = nullptr;
+    if (hipHostMalloc(&h, nb, hipHostMallocDefault) == hipSuccess) {
+        memset(h, 0, std::min<size_t>(nb, (size_t)1 << 20));
+        (void)hipMemcpyAsync(ctx->d_frames, h, std::min<size_t>(nb, (size_t)1 << 20), hipMemcpyHostToDevice, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    } else { h = nullptr; (void)hipGetLastError(); }
     HIPCHK(hipMemsetAsync(ctx->d_frames, 0, (size_t)n * ctx->g.fsz, ctx->stream));
     ctx->st_ahead = true;
-    if (int rc = encode_range(ctx, 0, n)) return rc;
+    int rc = encode_range(ctx, 0, n);
     uint64_t bits = 0;
     const int npk = (n / L) * L;
-    if (npk > 0) {
-        if (int rc = icsp_pack_count(ctx, 0, npk, &bits)) return rc;
-        if (int rc = pack_write(ctx, 0, npk, 0)) return rc;
+    if (!rc && npk > 0) {
+        rc = icsp_pack_count(ctx, 0, npk, &bits);
+        if (!rc) rc = pack_write(ctx, 0, npk, 0);
+        if (!rc && h) (void)hipMemcpyAsync(h, ctx->pk.out, std::min(nb, ctx->pk_cap), hipMemcpyDeviceToHost, ctx->stream);
     }
     ctx->pk_first = -1;
-    return icsp_sync(ctx);
+    if (!rc) rc = icsp_sync(ctx);
+    if (h) (void)hipHostFree(h);
+    return rc;
 }
 
 int icsp_encode_gop(icsp_ctx_t* ctx, const uint8_t* yuv, int n, int16_t* levels, uint8_t* acflag, uint8_t* mpm, int8_t* mvd, uint8_t* recon)

@@ -340,8 +340,18 @@ int main(int argc, char* argv[])
             return w->body != nullptr;
         };
         if (!w->rc && !opt.hostpack && !bin_pinned && !need_body(std::max<size_t>(cbytes / 2, (size_t)1 << 20))) { w->rc = ICSP_ERR_MEM_ALLOC; w->err = "pinned host memory"; }
-        // the first transfer into a newly pinned mapping costs its hipMemcpyAsync call about 6 ms: spend it now, on the string of
-        // icsp_prepare's black GOP, and clear those bytes again (the image has to start out zeroed)
+        // the first transfers from and into the newly pinned mappings can cost their hipMemcpyAsync calls milliseconds: spend
+        // that now.  One frame read from the input mapping (into slot 0, which the first chunk overwrites); the slots' content
+        // written into the output mapping; and, below, the black GOP's string into the .bin mapping, cleared again (the image
+        // has to start out zeroed).  icsp_prepare has spent the stream's own first-transfer costs already.
+        if (!w->rc) {
+            // (whatever the slots hold goes to frames [0, cmax) of the output, which their chunks write again)
+            if (in_map) (void)icsp_upload(w->ctx, in_map, 0, 1);
+            if (out_map) (void)icsp_download(w->ctx, 0, cmax, nullptr, nullptr, nullptr, nullptr, out_map);
+            (void)icsp_sync(w->ctx);
+        }
+        if (!w->rc && !opt.hostpack && bin_pinned && bin_est > 2 * page)
+            (void)icsp_host_warm(w->ctx, bin_map + page, bin_est - 2 * page);     // zeros: the black GOP's string is too short for a DMA
         if (!w->rc && !opt.hostpack && bin_pinned) {
             uint64_t b = 0;
             if (icsp_pack_count(w->ctx, 0, std::min(L, cmax), &b) == ICSP_OK && 14 + (size_t)(b / 8) + 2 <= bin_est &&

@@ -172,6 +172,10 @@ void icsp_host_free(void* p);
  * usable from every device.  ICSP_ERR_HIP when the runtime refuses the range (callers fall back to staging buffers). */
 int icsp_host_register(void* p, size_t bytes, int read_only);
 int icsp_host_unregister(void* p);
+/* Spends a pinned range's first-use cost now: the context's stream writes `bytes` zero bytes (at most 16 MB) to it by DMA.  For
+ * ranges that must start out zeroed anyway, i.e. the body image icsp_pack_into fills (a stream's first large transfer into a
+ * newly pinned range can cost the call about 6 ms). */
+int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes);
 
 /* ---- decoder side: DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp ---- */
 /* Host: readHeader (DEC:14-37).  intra_period is the header field as stored: 1 (or 0) = every frame intra (DEC.h:293). */
