@@ -122,6 +122,7 @@ struct Geo {
     int W, H, sw, sh, nmb, cols8, rows8, cw, ch;
     int qdc, qac;
     uint32_t mdc, mac;                // floor(2^32/q) + 1: |t|/q == umulhi(|t|, m) for |t| < 2^16, q > 1
+    uint32_t msw, mtpr;               // the same for sw and for the tiles per row (sw + 1) / 2: n / sw == umulhi(n, msw) for n < 2^16
     long long fsz;                    // bytes per frame = W*H*3/2
 };
 struct FrameSel { int first, stride, count; };     // item i -> frame slot first + i*stride
@@ -204,6 +205,7 @@ __device__ __forceinline__ int pad_fetch(const uint8_t* plane, int w, int h, int
 // When a launch has few frames (or they are large) a frame is cut into `slices` runs of consecutive units (bands of the
 // frame) and the (frame, slice) pairs are dealt over the XCDs instead, so that all 8 XCDs have work.
 struct XcdUnit { int frame, unit; };          // unit >= per_frame or frame >= frames: padding, the workgroup returns at once
+// 1-D form (k_serial_fused, whose grid has the serial workgroups in front): b = block index among the units' workgroups
 __device__ __forceinline__ XcdUnit xcd_unit(int b, int per_frame, int slices)
 {
     const int per_vf = (per_frame + slices - 1) / slices;           // everything here is wave-uniform: scalar arithmetic
@@ -212,11 +214,23 @@ __device__ __forceinline__ XcdUnit xcd_unit(int b, int per_frame, int slices)
     const int unit = slice * per_vf + (j - q * per_vf);
     return XcdUnit{ unit < per_frame ? frame : 0x7fffffff, unit };
 }
+// 2-D form: grid (8 * per_vf, ceil(frames * slices / 8)), x fastest, so the linear workgroup number -- and with it the XCD --
+// is what the 1-D form has, but the two quotients come as blockIdx.x >> 3 and blockIdx.y instead of by division (an integer
+// division of wave-uniform values still costs five vector instructions, one of them a reciprocal, and a dozen scalar
+// ones: with three of them a kernel spent 4 % of its instructions finding out which workgroup it is).  slices: a power of two.
+__device__ __forceinline__ XcdUnit xcd_unit2(int per_frame, int slices)
+{
+    const int sl = __builtin_ctz((unsigned)slices);
+    const int per_vf = (per_frame + slices - 1) >> sl;
+    const int vf = ((int)blockIdx.x & 7) + 8 * (int)blockIdx.y, frame = vf >> sl, slice = vf & (slices - 1);
+    const int unit = slice * per_vf + ((int)blockIdx.x >> 3);
+    return XcdUnit{ unit < per_frame ? frame : 0x7fffffff, unit };
+}
 int g_force_slices = 0;                                             // ICSP_XCD_SLICES (experiments); 0 = automatic
 inline int xcd_slices(int frames, int per_frame)
 {
-    if (g_force_slices > 0) return g_force_slices <= per_frame ? g_force_slices : per_frame;
     int s = 1;                                                      // a power of two up to 8: frames * s pairs deal out evenly ...
+    if (g_force_slices > 0) { while (2 * s <= g_force_slices && 2 * s <= per_frame) s *= 2; return s; }
     while (s < 8 && frames * s < 32 && per_frame / (2 * s) >= 32) s *= 2;       // ... in slices of at least 32 units
     return s;
 }
@@ -224,6 +238,11 @@ inline unsigned xcd_grid(int frames, int per_frame, int slices)
 {
     const int per_vf = (per_frame + slices - 1) / slices;
     return 8u * (unsigned)((frames * slices + 7) / 8) * (unsigned)per_vf;
+}
+inline dim3 xcd_grid2(int frames, int per_frame, int slices)
+{
+    const int per_vf = (per_frame + slices - 1) / slices;
+    return dim3(8u * (unsigned)per_vf, (unsigned)((frames * slices + 7) / 8));
 }
 
 #include "icsp_me.hip.inc"
@@ -469,7 +488,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         launch_timed(ctx, ICSP_K_INTRA_LUMA, st, [&] { launch_intra_luma(ctx, g, fs, b, G, G, st); });
         launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
-        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(G, cwgs, sc_)), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
+        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         ctx->s2_dirty = true;
         if (!lazy) join_s2(ctx);
         HIPCHK(hipGetLastError());
@@ -495,7 +514,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         FrameSel fs{ first, L, G };
         launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
-        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(G, cwgs, sc_)), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
+        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         hipEventRecord(ctx->ev_join, s2);
     }
     for (int k = 0; k < NG; k++) {
@@ -534,14 +553,14 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             run = run < 1 ? 1 : (run > 32 ? 32 : run);
             const int runs = (tiles + run - 1) / run, sf_ = xcd_slices(Gi, runs);
             launch_timed(ctx, ICSP_K_ME, sk, [&] {
-                hipLaunchKernelGGL((k_me<false>), dim3(xcd_grid(Gi, tiles, st_)), dim3(256), 0, sk, g, fs, b, tiles, st_, 1);
-                if (!fused) hipLaunchKernelGGL((k_me<true>), dim3(xcd_grid(Gi, runs, sf_)), dim3(256), 0, sk, g, fs, b, tiles, sf_, run);
+                hipLaunchKernelGGL((k_me<false>), xcd_grid2(Gi, tiles, st_), dim3(256), 0, sk, g, fs, b, tiles, st_, 1);
+                if (!fused) hipLaunchKernelGGL((k_me<true>), xcd_grid2(Gi, runs, sf_), dim3(256), 0, sk, g, fs, b, tiles, sf_, run);
             });
             launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
                 if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, runs, sf_)), dim3(256), serial_lds, sk, g, fs, b, (int)n_serial8, runs, sf_, run, tiles);
                 else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
             });
-            launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, dim3(xcd_grid(Gi, res_wgs, sr_)), dim3(256), 0, sk, g, fs, b, 1, res_wgs, sr_); });
+            launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(Gi, res_wgs, sr_), dim3(256), 0, sk, g, fs, b, 1, res_wgs, sr_); });
         }
         if (!any) break;
     }
@@ -723,6 +742,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     // strictly above 2^32/q, which the signed form in the DC chains needs (a negative multiple of q must not divide exactly)
     g.mdc = (uint32_t)(0x100000000ull / (unsigned)g.qdc + 1);               // unused when q == 1 (would not fit 32 bits)
     g.mac = (uint32_t)(0x100000000ull / (unsigned)g.qac + 1);
+    g.msw = (uint32_t)(0x100000000ull / (unsigned)g.sw + 1);
+    g.mtpr = (uint32_t)(0x100000000ull / (unsigned)((g.sw + 1) / 2) + 1);
     g.fsz = (long long)g.W * g.H * 3 / 2;
     ctx->intra_waves = intra_waves_needed(g);
     ctx->n_cu = 256;
