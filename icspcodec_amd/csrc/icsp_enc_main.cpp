@@ -277,6 +277,11 @@ int main(int argc, char* argv[])
     // With fewer devices than asked for, workers share devices round-robin, so every option still works on a one-GPU box.
     const int L = opt.intra_period > 0 ? opt.intra_period : 1;
     const int ngop = (n + L - 1) / L;
+    // Short clips copy with the runtime's shader kernels instead of its DMA engines: an engine's queue costs about 6 ms when
+    // a process first uses it, which engine a copy gets varies from run to run, and a clip that takes 2.4 ms after set-up
+    // then takes 10 ms in two runs of three (measured; eight of eight at 2.4 ms this way).  Long clips keep the engines, which
+    // move their data about 10 % faster beside the kernels.  (Decided before the runtime starts; never overrides the caller.)
+    if ((uint64_t)n * nmb <= (uint64_t)1024 * 396) setenv("HSA_ENABLE_SDMA", "0", 0);
     const int ndev_seen = icsp_device_count();                      // starts the HIP runtime
     hip_up.set();
     const int ndev = ndev_seen > 0 ? ndev_seen : 1;
