@@ -635,11 +635,12 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     // waves x 128 VGPRs so two workgroups share a CU and every frame of the batch is in flight at once (measured on
     // 300 CIF frames: 0.45 ms vs 0.57 ms).
     // 8-lane form (eight blocks per wave, k_intra_luma8): fewer instructions per block, more per wave and step.  It wins
-    // when the CUs are loaded anyway (more than two frames per CU) and on frames too wide for one round of the 32-lane form.
+    // when the CUs are loaded anyway (more than about 1.5 frames per CU: 512 frames 1.43 M against 1.32 M frames/s, 400 frames
+    // level, 300 frames 0.89 M against 0.90 M) and on frames too wide for one round of the 32-lane form.
     const int need = ctx->intra_waves;
     const int need8 = (need * 2 + 7) / 8;                           // waves of eight blocks for the widest step
     int form = ctx->force_intra_form;
-    if (!form) form = (G_all > 2 * ctx->n_cu || need > 16) ? 8 : 32;
+    if (!form) form = (2 * G_all > 3 * ctx->n_cu || need > 16) ? 8 : 32;    // measured crossover on CIF: about 1.5 frames per CU
     if (form == 8) {
         const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : need8;
         if (nw <= 1)       launch_intra8<1>(g, fs, b, G, st);
