@@ -79,6 +79,7 @@ def load() -> C.CDLL:
         lib.icsp_bitstream_end.argtypes = [vp, C.c_uint64]
         lib.icsp_host_register.argtypes = [vp, C.c_size_t, C.c_int]
         lib.icsp_host_unregister.argtypes = [vp]
+        lib.icsp_host_warm.argtypes = [vp, vp, C.c_size_t]
         lib.icsp_bitstream_assemble.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), vp, C.c_size_t,
                                                 C.POINTER(C.c_size_t)]
         lib.icsp_parse_header.argtypes = [vp, C.c_size_t, C.POINTER(Params)]
@@ -138,6 +139,15 @@ def finish_image(width, height, qp_dc, qp_ac, intra_period, image: np.ndarray, t
     if rc:
         raise RuntimeError(f"icsp_bitstream_header/end: {lib.icsp_strerror(rc).decode()}")
     return image[: n.value].tobytes()
+
+
+def host_register(a: np.ndarray, read_only=False) -> bool:
+    """Pins the array's memory for DMA (icsp_host_register); False when the runtime refuses."""
+    return load().icsp_host_register(_vp(a), a.nbytes, 1 if read_only else 0) == 0
+
+
+def host_unregister(a: np.ndarray) -> bool:
+    return load().icsp_host_unregister(_vp(a)) == 0
 
 
 def parse_header(bs: bytes) -> Params:
@@ -274,6 +284,10 @@ class Encoder:
     def pack_into(self, first, n, at_bit, body_image: np.ndarray):
         """Packs the range icsp_pack_count last measured at bit `at_bit` of the (zero-initialised) body image."""
         self._chk(self.lib.icsp_pack_into(self.ctx, first, n, at_bit, _vp(body_image), body_image.size), "icsp_pack_into")
+
+    def host_warm(self, pinned: np.ndarray):
+        """Zero bytes (at most 16 MB) written into a pinned range by DMA (icsp_host_warm)."""
+        self._chk(self.lib.icsp_host_warm(self.ctx, _vp(pinned), pinned.size), "icsp_host_warm")
 
     def prepare(self):
         self._chk(self.lib.icsp_prepare(self.ctx), "icsp_prepare")

@@ -1051,11 +1051,12 @@ int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes)
     HIPCHK(hipSetDevice(ctx->device));
     join_s2(ctx);
     if (int rc = pack_alloc(ctx)) return rc;
-    const size_t nb = std::min({ bytes, ctx->pk_cap, (size_t)16 << 20 });
+    const size_t nb = std::min(bytes, (size_t)16 << 20), piece = std::min(nb, ctx->pk_cap);
     if (nb == 0) return ICSP_OK;
     ctx->pk_first = -1;                                 // the scratch no longer holds a counted string
-    HIPCHK(hipMemsetAsync(ctx->pk.out, 0, nb, ctx->stream));
-    HIPCHK(hipMemcpyAsync(pinned, ctx->pk.out, nb, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemsetAsync(ctx->pk.out, 0, piece, ctx->stream));
+    for (size_t o = 0; o < nb; o += piece)
+        HIPCHK(hipMemcpyAsync((uint8_t*)pinned + o, ctx->pk.out, std::min(piece, nb - o), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ICSP_OK;
 }

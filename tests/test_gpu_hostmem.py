@@ -1,0 +1,71 @@
+"""Pinned host ranges the caller owns (icsp_host_register / icsp_host_unregister / icsp_host_warm): uploads from and downloads
+into a registered mapping of a file give the same bytes as plain arrays; the warm-up writes zeros only."""
+import mmap
+import os
+
+import numpy as np
+import pytest
+
+from icspcodec_amd import capi, clipgen
+
+pytestmark = pytest.mark.gpu
+W, H = 352, 288
+
+
+def test_registered_file_mappings_carry_the_same_bytes(tmp_path):
+    n, q, period = 12, 16, 6
+    clip = clipgen.synth_clip("foremanlike", n)
+    ref = capi.Encoder(W, H, q, q, period, max_frames=n)
+    want = ref.encode(clip)
+    ref.close()
+    fin, fout = tmp_path / "in.yuv", tmp_path / "out.yuv"
+    clip.tofile(fin)
+    with open(fout, "wb") as f:
+        f.truncate(clip.nbytes)
+    with open(fin, "rb") as fi, open(fout, "r+b") as fo:
+        mi = mmap.mmap(fi.fileno(), 0, access=mmap.ACCESS_READ)
+        mo = mmap.mmap(fo.fileno(), 0, access=mmap.ACCESS_WRITE)
+        src = np.frombuffer(mi, np.uint8)
+        dst = np.frombuffer(mo, np.uint8)
+        pinned_in = capi.host_register(src, read_only=True)
+        pinned_out = capi.host_register(dst)
+        enc = capi.Encoder(W, H, q, q, period, max_frames=n)
+        enc.prepare()
+        rc = enc.lib.icsp_upload(enc.ctx, capi._vp(src), 0, n)
+        assert rc == 0
+        enc.encode_resident(0, n)
+        rc = enc.lib.icsp_download(enc.ctx, 0, n, None, None, None, None, capi._vp(dst))
+        assert rc == 0
+        got = enc.download(0, n, what=("levels", "mvd"))
+        enc.close()
+        assert np.array_equal(got["levels"], want["levels"]) and np.array_equal(got["mvd"], want["mvd"])
+        assert np.array_equal(dst.reshape(want["recon"].shape), want["recon"])
+        if pinned_in:
+            assert capi.host_unregister(src)
+        if pinned_out:
+            assert capi.host_unregister(dst)
+        del src, dst
+        mi.close(); mo.close()
+    assert np.array_equal(np.fromfile(fout, np.uint8).reshape(want["recon"].shape), want["recon"])      # the file itself
+
+
+def test_host_warm_writes_zeros_only_and_keeps_a_count_from_leaking():
+    enc = capi.Encoder(W, H, 16, 16, 0, max_frames=4)
+    clip = clipgen.synth_clip("foremanlike", 4)
+    enc.upload(clip)
+    enc.encode_resident(0, 4)
+    bits = enc.pack_count(0, 4)
+    assert bits > 0
+    buf = np.full(3 << 20, 0xAB, np.uint8)
+    assert capi.host_register(buf)
+    enc.host_warm(buf[4096:])
+    assert not buf[4096:].any() and (buf[:4096] == 0xAB).all()
+    with pytest.raises(RuntimeError):                    # the scratch no longer holds the counted string
+        enc.pack_into(0, 4, 0, np.zeros(1 << 20, np.uint8))
+    assert enc.pack_count(0, 4) == bits
+    image = np.zeros(bits // 8 + 64, np.uint8)
+    enc.pack_into(0, 4, 0, image)
+    want, wbits = enc.pack_bits(0, 4)
+    assert wbits == bits and np.array_equal(image[: len(want)], want)
+    assert capi.host_unregister(buf)
+    enc.close()
