@@ -172,12 +172,13 @@ __device__ __forceinline__ int median3(int a, int b, int c)   // the reference's
 }
 __device__ __forceinline__ unsigned long long ballot64(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 // Lane mask of x != 0.  hipcc lowers a ballot whose condition has a second use (or sits next to one) to v_cmp, v_cndmask 0/1,
-// v_cmp again -- three vector instructions; this is the one v_cmp it should be.  The mask is for scalar use (tests, shifts):
-// a vector instruction reading it as a select would need the wait states the compiler cannot see here.
+// v_cmp again -- three vector instructions; this is the one v_cmp it should be.  gfx940-class parts need two wait states
+// between a vector instruction writing an SGPR and a vector instruction reading it; the compiler inserts them for its own
+// code but cannot see into this statement, so they are part of it.
 __device__ __forceinline__ unsigned long long ballot_ne0(int x)
 {
     unsigned long long m;
-    asm volatile("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(m) : "v"(x));
+    asm volatile("v_cmp_ne_u32_e64 %0, 0, %1\n\ts_nop 1" : "=s"(m) : "v"(x));
     return m;
 }
 __device__ __forceinline__ int med3i(int a, int b, int c) { return max(min(a, b), min(max(a, b), c)); }   // same value as median3, branch-free (v_med3_i32)
