@@ -203,10 +203,14 @@ def main():
         return reduce(dt, dist.ReduceOp.MAX), prof, (dom_ms, dom_n)
 
     def timed_passes(enc, n, passes):
-        """Big batches: two warm passes, then `passes` timed ones between barriers; max over ranks."""
-        for _ in range(2):
+        """Big batches: warm passes for at least 40 ms (two at the least: the GPU clock ramps), then `passes` timed ones
+        between barriers; max over ranks."""
+        t_w = time.perf_counter()
+        k = 0
+        while k < 2 or (time.perf_counter() - t_w < 0.04 and k < 50):
             enc.encode_resident(0, n)
-        enc.sync()
+            enc.sync()
+            k += 1
         barrier()
         t0 = time.perf_counter()
         for _ in range(passes):
