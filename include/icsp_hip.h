@@ -29,7 +29,7 @@
  *   ICSP_INTRA_NW  1..16 waves per workgroup of the intra luma kernel (rounded up to a built variant; default: from the
  *                        frame width and the batch size)
  *   ICSP_INTRA_FORM 8|32 lanes per 8x8 block in the intra luma kernel: 32 = latency form (two blocks per wave), 8 = throughput
- *                        form (eight blocks per wave); default: 8 when there are more than two frames per CU or the frame is
+ *                        form (eight blocks per wave); default: 8 when there are more than 1.5 frames per CU or the frame is
  *                        wider than one round of the 32-lane form, else 32
  *   ICSP_XCD_SLICES 0..64 bands a frame is cut into when a P step's workgroups are dealt over the XCDs (0 = automatic; rounded down to a power of two)
  * Threading: one context per device; calls on one context must be serialised by the caller; distinct
