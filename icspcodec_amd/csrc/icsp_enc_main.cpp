@@ -31,6 +31,8 @@
 //                   chunk, at most 3)
 //   --chunk F       frames per chunk (rounded up to whole GOPs; default: 512 CIF frames' worth of macroblocks)
 //   --staged        staging buffers instead of pinned file mappings
+//   --nopin         the files are mapped but not pinned, as when the runtime refuses the ranges (tests the fall-back: staging
+//                   buffers for frames and reconstruction, host placement of the bits into the unpinned .bin mapping)
 //   --binest B      bytes of the .bin mapping to populate and pin (default 30 % of the input + 1 MB); tests use it to push
 //                   chunks onto the host-placement path
 //   --width W --height H   frame size (the reference hard-codes 352x288, encoder_main.cpp:20)
@@ -63,7 +65,7 @@ enum { SUCCESS = 0, UNENOUGH_PARAM, UNCORRECT_PARAM, FAIL_MEM_ALLOC };
 struct Options {
     char yuv_fname[256];
     int total_frames, qp_dc, qp_ac, intra_period, multi_thread_mode, nthreads;
-    int gpus, width, height, hostpack, streams, stats, staged, chunk;
+    int gpus, width, height, hostpack, streams, stats, staged, chunk, nopin;
     long long binest;
 };
 
@@ -124,6 +126,7 @@ int parsing_command(int argc, char* argv[], Options* cmd)
             else if (!strcmp(name, "hostpack")) cmd->hostpack = 1;
             else if (!strcmp(name, "stats")) cmd->stats = 1;
             else if (!strcmp(name, "staged")) cmd->staged = 1;
+            else if (!strcmp(name, "nopin")) cmd->nopin = 1;
             else if (!strcmp(name, "chunk")) cmd->chunk = atoi(val);
             else if (!strcmp(name, "binest")) cmd->binest = atoll(val);
             else return UNCORRECT_PARAM;
@@ -264,9 +267,10 @@ int main(int argc, char* argv[])
             t_map = now() - t0;
             hip_up.wait();
             const double t1 = now();
-            if (in_raw != MAP_FAILED && icsp_host_register(in_raw, total_bytes, 1) == ICSP_OK) in_map = (uint8_t*)in_raw;
-            if (out_raw != MAP_FAILED && icsp_host_register(out_raw, total_bytes, 0) == ICSP_OK) out_map = (uint8_t*)out_raw;
-            if (bin_raw != MAP_FAILED) { bin_map = (uint8_t*)bin_raw; bin_pinned = icsp_host_register(bin_raw, bin_est, 0) == ICSP_OK; }
+            const bool pin = !opt.nopin;                          // --nopin: behave as if the runtime had refused every range
+            if (pin && in_raw != MAP_FAILED && icsp_host_register(in_raw, total_bytes, 1) == ICSP_OK) in_map = (uint8_t*)in_raw;
+            if (pin && out_raw != MAP_FAILED && icsp_host_register(out_raw, total_bytes, 0) == ICSP_OK) out_map = (uint8_t*)out_raw;
+            if (bin_raw != MAP_FAILED) { bin_map = (uint8_t*)bin_raw; bin_pinned = pin && icsp_host_register(bin_raw, bin_est, 0) == ICSP_OK; }
             t_pin = now() - t1;
         }
         maps_settled.set();

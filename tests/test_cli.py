@@ -39,7 +39,8 @@ def test_option_errors_match_reference_messages_and_exit_code(tmp_path):
                                           (0, ["--hostpack"]), (6, ["--staged"]), (0, ["--staged", "--chunk", "5"]),
                                           (6, ["--chunk", "6", "--streams", "2"]), (6, ["--staged", "--hostpack", "--chunk", "1"]),
                                           (6, ["--chunk", "6", "--streams", "2", "--binest", "200000"]),
-                                          (0, ["--chunk", "3", "--streams", "3", "--binest", "4096"])])
+                                          (0, ["--chunk", "3", "--streams", "3", "--binest", "4096"]),
+                                          (6, ["--nopin", "--chunk", "6", "--streams", "2"]), (0, ["--nopin"])])
 def test_cli_outputs_equal_reference_files(tmp_path, golden_dir, period, extra):
     n, qp = 12, 16
     clip = clipgen.synth_clip("foremanlike", n)
