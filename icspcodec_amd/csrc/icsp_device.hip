@@ -81,6 +81,9 @@ __constant__ ZigZagCol c_zzcol = make_zigzag_col();
 struct MeTables {
     int8_t  un_dx[132], un_dy[132];   // the 129 distinct offsets of the four walks
     uint8_t walk_u[4][64];            // (state, step) -> index into un_*
+    uint32_t pack[144];               // per offset u (the last one repeated to 144): what k_me keeps in LDS, precomputed --
+                                      //   low half: dword offset of the candidate's first window row | byte shift << 14,
+                                      //   high half: (dx & 0xff) | (dy & 0xff) << 8
     int     n_union;
 };
 __constant__ MeTables c_me;
@@ -373,6 +376,11 @@ void build_me_tables(MeTables& t)
         }
     }
     t.n_union = n;
+    for (int u = 0; u < 144; u++) {
+        const int v = u < n ? u : n - 1;
+        const int dx = t.un_dx[v], dy = t.un_dy[v], ox = 16 + dx, oy = 16 + dy;
+        t.pack[u] = (uint32_t)((oy * kWinDw + (ox >> 2)) | ((ox & 3) << 14)) | (uint32_t)((dx & 0xff) | ((dy & 0xff) << 8)) << 16;
+    }
 }
 
 int collect_profile(icsp_ctx* ctx);
