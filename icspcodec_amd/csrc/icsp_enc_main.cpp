@@ -245,9 +245,11 @@ int main(int argc, char* argv[])
     const bool want_map = !opt.staged && 2 * total_bytes <= kMapCap;
     const size_t page = (size_t)sysconf(_SC_PAGESIZE);
     const size_t bin_cap = icsp_bitstream_bound(&params, n) + 2;    // worst case, header included
-    // (the part populated and pinned: 30 % of the input + 1 MB covers QP >= 8 on camera-like content; strings that end
-    //  beyond it come back through a pinned buffer and are placed by the host.  --binest BYTES overrides, for tests)
-    const size_t bin_guess = opt.binest > 0 ? (size_t)opt.binest : 14 + total_bytes * 3 / 10 + ((size_t)1 << 20);
+    // (the part populated and pinned: 30 % of the input + 1 MB for all-intra, 24 % with P frames -- what QP >= 8 needs on
+    //  camera-like content, and every populated page the stream does not use costs time twice, allocated and freed again;
+    //  strings that end beyond it come back through a pinned buffer and are placed by the host.  --binest BYTES overrides)
+    const size_t bin_guess = opt.binest > 0 ? (size_t)opt.binest
+                                            : 14 + total_bytes * (opt.intra_period > 1 ? 24 : 30) / 100 + ((size_t)1 << 20);
     const size_t bin_est = std::min(bin_cap, (bin_guess + page - 1) / page * page);
     uint8_t* in_map = nullptr; uint8_t* out_map = nullptr;           // non-null only when mapped AND pinned
     uint8_t* bin_map = nullptr;                                      // the .bin mapping (bin_cap bytes), pinned or not
