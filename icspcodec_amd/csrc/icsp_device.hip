@@ -914,13 +914,25 @@ int icsp_decode_resident(icsp_ctx_t* ctx, int first, int n)
 
 // ---- device bit packer (icsp_pack.hip.inc).  Two steps: lengths + scans (the host learns the number of bits), then the
 // packing itself at a bit phase the host chooses.
+// bytes of body buffer for a string of `bits` bits: + the byte phase icsp_pack_into may place it at (< 64), + the dwords past
+// the end that k_pack_zero clears, rounded to a dword
+static inline size_t pack_bytes(unsigned long long bits) { return ((size_t)(bits / 8) + 1 + 64 + 16 + 3) & ~(size_t)3; }
+
 static int pack_alloc(icsp_ctx* ctx)
 {
     if (ctx->pk.out) return ICSP_OK;
+    if (ctx->pk.grp_bits) {                                            // (a failed pack_reserve left only the body buffer missing)
+        if (hipMalloc((void**)&ctx->pk.out, ctx->pk_cap = pack_bytes(8ull << 20)) == hipSuccess) return ICSP_OK;
+        (void)hipGetLastError(); ctx->pk.out = nullptr; ctx->pk_cap = 0; ctx->err = "hipMalloc bit packer body";
+        return ICSP_ERR_MEM_ALLOC;
+    }
     const Geo& g = ctx->g;
     const long long cap_grps = ((long long)ctx->max_frames * g.nmb * 6 + kGrpUnits - 1) / kGrpUnits;
     const size_t chunks = (size_t)((cap_grps + kChunkGrps - 1) / kChunkGrps);
-    ctx->pk_cap = (icsp_bitstream_bound(&ctx->p, ctx->max_frames) + 64 + 16 + 3) & ~(size_t)3;     // + the byte phase of icsp_pack_into
+    // the body buffer starts at a third of the frames' size (what QP >= 8 needs) and grows to what a count asks for
+    // (pack_reserve): the worst case, seven times the frames, would be gigabytes that almost no stream ever touches
+    ctx->pk_cap = std::min(pack_bytes(icsp_bitstream_bound(&ctx->p, ctx->max_frames) * 8ull),
+                           pack_bytes((unsigned long long)ctx->max_frames * (unsigned long long)ctx->g.fsz * 8ull / 3 + (8ull << 20)));
     hipError_t e = hipSuccess;
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.grp_bits, (size_t)cap_grps * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.grp_off, (size_t)cap_grps * sizeof(uint32_t));
@@ -935,6 +947,23 @@ static int pack_alloc(icsp_ctx* ctx)
         ctx->err = std::string("hipMalloc bit packer: ") + hipGetErrorString(e);
         return ICSP_ERR_MEM_ALLOC;
     }
+    return ICSP_OK;
+}
+
+// makes room in the body buffer for a string of `bits` bits at any phase icsp_pack_into may ask for; a realloc drops whatever
+// the buffer held (nothing does between a count and its packing)
+static int pack_reserve(icsp_ctx* ctx, unsigned long long bits)
+{
+    const size_t need = pack_bytes(bits);
+    if (need <= ctx->pk_cap) return ICSP_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    hipFree(ctx->pk.out); ctx->pk.out = nullptr; ctx->pk_cap = 0;
+    const size_t want = need + need / 4;                               // headroom: the next batches are about as long
+    if (hipMalloc((void**)&ctx->pk.out, want) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipMalloc((void**)&ctx->pk.out, need) != hipSuccess) { ctx->pk.out = nullptr; ctx->err = "hipMalloc bit packer body"; (void)hipGetLastError(); return ICSP_ERR_MEM_ALLOC; }
+        ctx->pk_cap = need;
+    } else ctx->pk_cap = want;
     return ICSP_OK;
 }
 
@@ -971,6 +1000,7 @@ int icsp_pack_count(icsp_ctx_t* ctx, int first, int n, uint64_t* nbits)
     unsigned long long* total = (unsigned long long*)ctx->pk_host;
     HIPCHK(hipMemcpyAsync(total, pk.chunk_base + nchunk, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (int rc = pack_reserve(ctx, *total)) return rc;
     ctx->pk_first = first; ctx->pk_n = n; ctx->pk_total = *total;
     *nbits = *total;
     return ICSP_OK;
