@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -810,8 +811,16 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     hipMemsetAsync(ctx->b.mvd, 0, nf * nmb * 2, ctx->stream);
     hipMemsetAsync(ctx->b.mv, 0, nf * nmb * 2, ctx->stream);
     hipMemsetAsync(ctx->b.imode, 0, nf * nmb * 4, ctx->stream);
-    MeTables t; build_me_tables(t);
-    if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_me), &t, sizeof(t))) != hipSuccess) return fail(ICSP_ERR_HIP, "hipMemcpyToSymbol", e);
+    {   // the search tables are the same for every context: once per device and process (the call costs 7-12 ms)
+        static std::mutex m;
+        static bool loaded[64] = {};
+        std::lock_guard<std::mutex> lock(m);
+        if (device_id >= 64 || !loaded[device_id]) {
+            MeTables t; build_me_tables(t);
+            if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_me), &t, sizeof(t))) != hipSuccess) return fail(ICSP_ERR_HIP, "hipMemcpyToSymbol", e);
+            if (device_id < 64) loaded[device_id] = true;
+        }
+    }
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamSynchronize", e);
     *out = ctx;
     return ICSP_OK;
