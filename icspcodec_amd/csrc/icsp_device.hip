@@ -326,8 +326,6 @@ struct icsp_ctx {
     hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
     hipEvent_t ev_pjoin[kMaxPGroups];
     hipEvent_t ev_cjoin[kMaxPGroups]; // group k's I-frame chroma is done (recorded on stream2)
-    hipEvent_t ev_stagger;            // group 0's I-frame luma kernel is done (once per run of same-range encodes)
-    bool staggered;
     DevBufs b;
     PackBufs pk;                      // device bit packer scratch + body buffer, allocated on first icsp_pack_bits
     size_t pk_cap;                    // bytes of pk.out
@@ -468,7 +466,6 @@ int group_streams(icsp_ctx* ctx, int ng)
         }
     for (int k = 0; k < ng && k < kMaxPGroups; k++)
         if (!ctx->ev_cjoin[k]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_cjoin[k], hipEventDisableTiming));
-    if (!ctx->ev_stagger) HIPCHK(hipEventCreateWithFlags(&ctx->ev_stagger, hipEventDisableTiming));
     return 0;
 }
 
@@ -523,8 +520,6 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // kernels write (reconstruction of the I frames) --, then its chain on its own stream: luma kernel, wait for that chroma.
     // The groups stay independent of each other: a group's chroma waits for nothing of the other group.
     hipEventRecord(ctx->ev_fork, st);
-    if (!same) ctx->staggered = false;
-    const bool stagger_now = same && NG == 2 && !ctx->staggered;
     for (int k = 0; k < NG; k++) {
         const int g0 = group_lo(k), g1 = group_lo(k + 1);
         hipStream_t sk = k == 0 ? st : ctx->pstream[k];
@@ -536,16 +531,9 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         const int sc_ = xcd_slices(g1 - g0, cwgs);
         launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(g1 - g0, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         hipEventRecord(ctx->ev_cjoin[k], s2);
-        // Half a pass of one group is its I frames (a few CUs, pure latency), the other half its P steps (the whole chip):
-        // two groups in step collide kernel for kernel, two groups half a pass apart hardly at all.  Once per run of
-        // same-range encodes the second group is held back until the first one's luma kernel is through; from then on
-        // both chains run freely on their streams and keep that distance (configs[2]: 0.51 -> 0.47 ms per pass).
-        if (stagger_now && k == 1) hipStreamWaitEvent(sk, ctx->ev_stagger, 0);
         launch_timed(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fs, b, g1 - g0, G, sk); });
-        if (stagger_now && k == 0) hipEventRecord(ctx->ev_stagger, sk);
         hipStreamWaitEvent(sk, ctx->ev_cjoin[k], 0);
     }
-    if (stagger_now) ctx->staggered = true;
     ctx->s2_dirty = false;                             // `stream` is ordered after the chroma stream's work (the wait above)
     ctx->st_ahead = true;
     ctx->p_dirty = NG > 1;
@@ -779,7 +767,6 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     int no_fuse = 0;
     ctx->force_intra_nw = 0; ctx->force_intra_form = 0;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; ctx->ev_cjoin[k] = nullptr; }
-    ctx->ev_stagger = nullptr; ctx->staggered = false;
     ctx->p_groups = 2;                 // measured: 2 groups +7 %, 3 no better, more streams than hardware queues collapse
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) ||
         !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
@@ -855,7 +842,6 @@ int icsp_destroy(icsp_ctx_t* ctx)
     if (ctx->pk_host) hipHostFree(ctx->pk_host);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
-    if (ctx->ev_stagger) hipEventDestroy(ctx->ev_stagger);
     for (int k = 0; k < kMaxPGroups; k++) if (ctx->ev_cjoin[k]) hipEventDestroy(ctx->ev_cjoin[k]);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) hipEventDestroy(ctx->ev_pjoin[k]); if (ctx->pstream[k]) hipStreamDestroy(ctx->pstream[k]); }
