@@ -274,8 +274,8 @@ def main():
         clip2 = clipgen.synth_clip("stefanlike", NFRAMES, first_frame=rank * NFRAMES)
         enc2 = capi.Encoder(W, H, 8, 8, 10, device=local, max_frames=NFRAMES)
         enc2.upload(clip2)
-        steps2 = max(2, a.steps // 2)
-        dt2, prof2, _ = timed(enc2, NFRAMES, steps2, min(a.warmup, 2), None)      # no events inside this timed region
+        steps2 = max(2, a.steps)
+        dt2, prof2, _ = timed(enc2, NFRAMES, steps2, a.warmup, None)      # no events inside this timed region
         recon2 = enc2.download(0, NFRAMES, what=("recon",))["recon"]
         psnr_ip = clipgen.psnr_y(clip2, recon2, W, H)
         if rank == 0:

@@ -306,16 +306,15 @@ struct icsp_ctx {
     icsp_params_t p;
     Geo g;
     int device, max_frames, intra_waves, n_cu;
-    hipStream_t stream, stream2;      // stream2: I-frame chroma beside the luma wavefront kernel
+    hipStream_t stream, stream2;      // stream2: I-frame chroma beside the luma wavefront kernel (all-intra); all I-frame kernels (IPPP)
     hipEvent_t ev_fork, ev_join;
     // all-intra batches: stream2's chroma work and the luma kernel touch disjoint data, so consecutive encodes need no
     // cross-stream events at all; the join is deferred until something reads results (s2_dirty), the fork happens only
     // after other work was queued on `stream` (st_ahead) or when an outside producer uses the stream (always_sync)
     bool s2_dirty, st_ahead, always_sync;
-    // IPPP batches: every GOP group is a chain of its own (I frames, then its P steps) on its own stream, and consecutive
-    // encodes of the SAME range keep the chains independent across calls (no join, no fork: a slot is only ever touched by its
-    // group's stream).  p_dirty: the extra group streams carry work `stream` has not been ordered after yet; last_first /
-    // last_n: the range that work belongs to.
+    // IPPP batches: the I frames run on stream2, every GOP group's P steps are a chain on the group's own stream, and
+    // consecutive encodes of the SAME range overlap across calls as far as the data allow (encode_range).  p_dirty: the group
+    // streams carry work `stream` has not been ordered after yet; last_first / last_n: the range that work belongs to.
     bool p_dirty;
     int last_first, last_n;
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
@@ -325,7 +324,7 @@ struct icsp_ctx {
                                       // milliseconds to create, and an all-intra encode never needs them)
     hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
     hipEvent_t ev_pjoin[kMaxPGroups];
-    hipEvent_t ev_cjoin[kMaxPGroups]; // group k's I-frame chroma is done (recorded on stream2)
+    hipEvent_t ev_p1[kMaxPGroups];    // group k's first P step of the last IPPP pass is done (recorded on the group's stream)
     DevBufs b;
     PackBufs pk;                      // device bit packer scratch + body buffer, allocated on first icsp_pack_bits
     size_t pk_cap;                    // bytes of pk.out
@@ -465,7 +464,7 @@ int group_streams(icsp_ctx* ctx, int ng)
             HIPCHK(hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming));
         }
     for (int k = 0; k < ng && k < kMaxPGroups; k++)
-        if (!ctx->ev_cjoin[k]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_cjoin[k], hipEventDisableTiming));
+        if (!ctx->ev_p1[k]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_p1[k], hipEventDisableTiming));
     return 0;
 }
 
@@ -507,36 +506,31 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         HIPCHK(hipGetLastError());
         return 0;
     }
-    // ---- IPPP.  Every group is one chain on its stream: its I frames (luma), then its P steps.  The chroma of all I frames
-    // runs once on the chroma stream; every chain waits for it before its first P step (the luma kernel is ten times longer,
-    // so that wait is over before it is reached).  When this call encodes the same range as the one before and nothing else
-    // has touched the context since, the chains stay independent across the calls: a slot is only ever touched by its group's
-    // stream, so group 1 may still be finishing the previous pass while group 0 starts this one.  Anything else first joins
-    // everything onto `stream` (join_s2).
+    // ---- IPPP.  The I frames of all groups run on stream2 (chroma kernels, then the luma wavefront kernel); every group's P
+    // steps are one chain on the group's own stream, which waits for the I frames.  When this call encodes the same range as
+    // the one before and nothing else has touched the context since, the passes overlap as far as the data allow: a group's
+    // chain follows its own previous pass in stream order, and the I frames only wait for the FIRST P step of every group's
+    // previous pass -- the last reader of what the I kernels overwrite (the I frames' reconstruction; later P steps read and
+    // write their own slots and the slot before them only).  So the I frames of pass N+1, a latency-bound launch on a few
+    // CUs, run beside P steps 2.. of pass N instead of in front of an idle chip.  Anything else first joins everything onto
+    // `stream` (join_s2).
     const bool same = ctx->p_dirty && !ctx->always_sync && ctx->last_first == first && ctx->last_n == n;
     if (!same) join_s2(ctx);
     if (int rc = group_streams(ctx, NG)) return rc;
-    // Per group k: its I frames' chroma on the chroma stream -- after the group's previous pass, whose chain read what these
-    // kernels write (reconstruction of the I frames) --, then its chain on its own stream: luma kernel, wait for that chroma.
-    // The groups stay independent of each other: a group's chroma waits for nothing of the other group.
-    hipEventRecord(ctx->ev_fork, st);
-    for (int k = 0; k < NG; k++) {
-        const int g0 = group_lo(k), g1 = group_lo(k + 1);
-        hipStream_t sk = k == 0 ? st : ctx->pstream[k];
-        if (k == 0) hipStreamWaitEvent(s2, ctx->ev_fork, 0);
-        else if (same) { hipEventRecord(ctx->ev_pjoin[k], sk); hipStreamWaitEvent(s2, ctx->ev_pjoin[k], 0); }
-        else hipStreamWaitEvent(sk, ctx->ev_fork, 0);              // a chain starts after what was queued on `stream` (uploads ...)
-        FrameSel fs{ first + g0 * L, L, g1 - g0 };
-        launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(g1 - g0, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
-        const int sc_ = xcd_slices(g1 - g0, cwgs);
-        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(g1 - g0, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
-        hipEventRecord(ctx->ev_cjoin[k], s2);
-        launch_timed(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fs, b, g1 - g0, G, sk); });
-        hipStreamWaitEvent(sk, ctx->ev_cjoin[k], 0);
+    if (same) { for (int k = 0; k < NG; k++) hipStreamWaitEvent(s2, ctx->ev_p1[k], 0); }
+    else { hipEventRecord(ctx->ev_fork, st); hipStreamWaitEvent(s2, ctx->ev_fork, 0); }   // after what was queued on `stream` (uploads ...)
+    {
+        FrameSel fs{ first, L, G };
+        launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
+        const int sc_ = xcd_slices(G, cwgs);
+        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
+        launch_timed(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2); });
+        hipEventRecord(ctx->ev_join, s2);
+        for (int k = 0; k < NG; k++) hipStreamWaitEvent(k == 0 ? st : ctx->pstream[k], ctx->ev_join, 0);
     }
-    ctx->s2_dirty = false;                             // `stream` is ordered after the chroma stream's work (the wait above)
+    ctx->s2_dirty = false;                             // every chain, `stream` among them, is ordered after stream2's work
     ctx->st_ahead = true;
-    ctx->p_dirty = NG > 1;
+    ctx->p_dirty = true;
     ctx->last_first = first; ctx->last_n = n;
     for (int i = 1; i < L; i++) {
         bool any = false;
@@ -544,9 +538,9 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             const int g0 = group_lo(k), g1 = group_lo(k + 1);
             int Gi = 0;
             for (int gop = g0; gop < g1; gop++) if (gop * L + i < n) Gi++;
-            if (Gi == 0) continue;
-            any = true;
             hipStream_t sk = k == 0 ? st : ctx->pstream[k];
+            if (Gi == 0) { if (i == 1) hipEventRecord(ctx->ev_p1[k], sk); continue; }
+            any = true;
             FrameSel fs{ first + g0 * L + i, L, Gi };
             const size_t serial_lds = serial_lds_bytes(g.nmb, g.sw, g.sh);
             // small frames: the four-state search rides in the serial kernel's launch (one kernel boundary less per step;
@@ -571,6 +565,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
                 else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
             });
             launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(Gi, res_wgs, sr_), dim3(256), 0, sk, g, fs, b, 1, res_wgs, sr_); });
+            if (i == 1) hipEventRecord(ctx->ev_p1[k], sk);             // the I frames of the next pass may start
         }
         if (!any) break;
     }
@@ -766,8 +761,9 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->p_dirty = false; ctx->last_first = -1; ctx->last_n = -1;
     int no_fuse = 0;
     ctx->force_intra_nw = 0; ctx->force_intra_form = 0;
-    for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; ctx->ev_cjoin[k] = nullptr; }
-    ctx->p_groups = 2;                 // measured: 2 groups +7 %, 3 no better, more streams than hardware queues collapse
+    for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; ctx->ev_p1[k] = nullptr; }
+    ctx->p_groups = 2;                 // measured (300 CIF frames, period 10): 1 group 0.75 M frames/s, 2 groups 0.89 M, 3 groups -- a fourth
+                                       // busy stream of the context -- 0.27 M, whatever the stream priorities and GPU_MAX_HW_QUEUES
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) ||
         !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
         (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32) ||
@@ -842,7 +838,7 @@ int icsp_destroy(icsp_ctx_t* ctx)
     if (ctx->pk_host) hipHostFree(ctx->pk_host);
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
-    for (int k = 0; k < kMaxPGroups; k++) if (ctx->ev_cjoin[k]) hipEventDestroy(ctx->ev_cjoin[k]);
+    for (int k = 0; k < kMaxPGroups; k++) if (ctx->ev_p1[k]) hipEventDestroy(ctx->ev_p1[k]);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) hipEventDestroy(ctx->ev_pjoin[k]); if (ctx->pstream[k]) hipStreamDestroy(ctx->pstream[k]); }
     if (ctx->stream) hipStreamDestroy(ctx->stream);

@@ -161,3 +161,31 @@ def test_four_contexts_share_one_device_flagged():
     for t in th:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("name,n,q,period,groups", [("stefanlike", 83, 8, 10, 2), ("foremanlike", 41, 16, 10, 2), ("stefanlike", 40, 8, 10, 1),
+                                                    ("foremanlike", 7, 16, 10, 2), ("foremanlike", 1, 16, 10, 2),
+                                                    ("staticlike", 24, 16, 2, 2), ("stefanlike", 33, 8, 3, 2)])
+def test_back_to_back_passes_of_one_range_overlap(name, n, q, period, groups, monkeypatch):
+    """encode_range called again and again on the same resident range without a sync in between: the I frames of pass N+1 run
+    beside P steps 2.. of pass N (icsp_device.hip, encode_range).  Ragged ends (a last GOP that stops before, at, or after its
+    first P frame; a lone I frame), one and two GOP groups; then a different range, an upload and a last pass."""
+    monkeypatch.setenv("ICSP_P_GROUPS", str(groups))
+    clip = clipgen.synth_clip(name, n)
+    want = po.encode_sequence(clip, W, H, q, q, period)
+    enc = capi.Encoder(W, H, q, q, period, max_frames=n)
+    enc.upload(clip)
+    for _ in range(6):
+        enc.encode_resident(0, n)
+    _cmp(enc.download(0, n), want, "six passes")
+    if n > period:                                       # another range in between, then the whole again, twice
+        enc.encode_resident(period, n - period)
+        enc.encode_resident(0, n)
+        enc.encode_resident(0, n)
+        _cmp(enc.download(0, n), want, "after a sub-range")
+    other = clipgen.synth_clip("mobilelike" if name != "mobilelike" else "foremanlike", n)
+    enc.upload(other)                                    # new input: the next pass must not start before the upload has landed
+    enc.encode_resident(0, n)
+    enc.encode_resident(0, n)
+    _cmp(enc.download(0, n), po.encode_sequence(other, W, H, q, q, period), "after an upload")
+    enc.close()
