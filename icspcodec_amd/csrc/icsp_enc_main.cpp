@@ -307,6 +307,9 @@ int main(int argc, char* argv[])
     // Several workers on a device already keep it busy from several streams; a second GOP-group stream in each context only
     // adds queues to share (3000 frames, 3 workers: 18.0 ms with one group each, 19-22 ms with two).  Read by icsp_create.
     if (nworker > ndev) setenv("ICSP_P_GROUPS", "1", 0);
+    // An all-intra batch in two parts only pays when the same resident range is encoded again and again (a part then follows
+    // its own previous pass); every chunk here is encoded once.
+    setenv("ICSP_I_GROUPS", "1", 0);
     chunk_gops = std::max(1, std::min(chunk_gops, (ngop + nworker - 1) / nworker));     // every worker gets something to do
     const int chunk = chunk_gops * L;
     std::vector<Chunk> chunks;

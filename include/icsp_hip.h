@@ -26,6 +26,7 @@
  * that is not a whole number in the stated range makes icsp_create fail with ICSP_ERR_UNCORRECT_PARAM):
  *   ICSP_NO_FUSE   0|1   1: a P step's four-state motion search and the per-frame serial kernel run as two launches instead of one
  *   ICSP_P_GROUPS  1..3  number of GOP groups whose P-step kernel chains run on separate streams (default 2)
+ *   ICSP_I_GROUPS  1..2  parts (launches on separate streams) an all-intra batch of more frames than CUs is encoded in (default 2)
  *   ICSP_INTRA_NW  1..16 waves per workgroup of the intra luma kernel (rounded up to a built variant; default: from the
  *                        frame width and the batch size)
  *   ICSP_INTRA_FORM 8|32 lanes per 8x8 block in the intra luma kernel: 32 = latency form (two blocks per wave), 8 = throughput

@@ -82,3 +82,57 @@ def test_default_picks_the_8_lane_form_on_a_loaded_chip():
     assert hashlib.sha256(rec[:300].tobytes()).hexdigest() == ref["recon_sha256"]
     assert hashlib.sha256(rec[300:].tobytes()).hexdigest() == ref["recon_sha256"]
     assert hashlib.sha256(bs).hexdigest() == ref["bin_sha256"]
+
+
+@pytest.mark.parametrize("parts", ["1", "2"])
+def test_all_intra_batch_in_two_parts_back_to_back(parts):
+    """More frames than CUs: the luma kernel goes out as two launches on two streams (ICSP_I_GROUPS, encode_range), and
+    passes over the same range follow each other part by part without a join.  Back-to-back passes, a smaller range on the
+    same slots in between (one launch again), new input, and a context that shares the device."""
+    import hashlib
+    import json
+    os.environ["ICSP_I_GROUPS"] = parts
+    try:
+        clip = clipgen.synth_clip("foremanlike", 300)
+        ref = next(s for s in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "streams.json")))
+                   if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", 300, 16, 0) and "bin_sha256" in s)
+        enc = capi.Encoder(352, 288, 16, 16, 0, max_frames=300)
+        other_ctx = capi.Encoder(352, 288, 16, 16, 0, max_frames=300)
+        enc.upload(clip)
+        other_ctx.upload(clip)
+        for _ in range(5):
+            enc.encode_resident(0, 300)
+            other_ctx.encode_resident(0, 300)
+
+        def check(e, what):
+            rec = e.download(0, 300, what=("recon",))["recon"]
+            assert hashlib.sha256(rec.tobytes()).hexdigest() == ref["recon_sha256"], what
+            assert hashlib.sha256(e.pack_bitstream(0, 300)).hexdigest() == ref["bin_sha256"], what
+        check(enc, "five passes")
+        check(other_ctx, "five passes, second context")
+        other_ctx.close()
+        enc.encode_resident(0, 100)
+        enc.encode_resident(0, 300)
+        enc.encode_resident(0, 300)
+        check(enc, "after a smaller range")
+        other = clipgen.synth_clip("mobilelike", 300)
+        enc.upload(other)
+        enc.encode_resident(0, 300)
+        enc.encode_resident(0, 300)
+        got = enc.download(0, 300)
+        enc.close()
+    finally:
+        del os.environ["ICSP_I_GROUPS"]
+    _cmp(got, po.encode_sequence(other, 352, 288, 16, 16, 0, nthreads=NT), f"parts={parts}, new input: ")
+
+
+@pytest.mark.parametrize("var,val", [("ICSP_I_GROUPS", "3"), ("ICSP_P_GROUPS", "0"), ("ICSP_NO_FUSE", "yes"), ("ICSP_INTRA_FORM", "16"),
+                                     ("ICSP_INTRA_NW", "17"), ("ICSP_XCD_SLICES", "-1"), ("ICSP_I_GROUPS", "")])
+def test_override_outside_its_range_fails_the_create(var, val):
+    """include/icsp_hip.h: a tuning override that is not a whole number in its range makes icsp_create fail."""
+    os.environ[var] = val
+    try:
+        with pytest.raises(RuntimeError):
+            capi.Encoder(352, 288, 16, 16, 0, max_frames=2)
+    finally:
+        del os.environ[var]

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """The workload of the rocprofv3 --pmc passes: BASELINE configs[1] (300 CIF frames all-intra QP16) and configs[2] (300 frames,
---intraPeriod 10, QP8), three resident encode passes each (counters are per dispatch, kernels are serialised by the profiler)."""
+--intraPeriod 10, QP8), three resident encode passes each (counters are per dispatch, kernels are serialised by the profiler).
+The all-intra batch goes out as ONE launch of the luma kernel here (ICSP_I_GROUPS=1; the default is two launches on two streams,
+which the profiler would serialise anyway): the counters of that launch are those of a bench step's launches together."""
 import os, sys
+os.environ["ICSP_I_GROUPS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from icspcodec_amd import capi, clipgen
 for name, q, period in (("foremanlike", 16, 0), ("stefanlike", 8, 10)):
