@@ -308,6 +308,8 @@ struct icsp_ctx {
     int device, max_frames, intra_waves, n_cu;
     hipStream_t stream, stream2;      // stream2: I-frame chroma beside the luma wavefront kernel (all-intra); all I-frame kernels (IPPP)
     hipEvent_t ev_fork, ev_join;
+    hipStream_t up_stream, down_stream;   // icsp_copy_streams: the device's shared transfer streams (null: transfers on `stream`)
+    hipEvent_t ev_c1, ev_c2;
     // all-intra batches: stream2's chroma work and the luma kernel touch disjoint data, so consecutive encodes need no
     // cross-stream events at all; the join is deferred until something reads results (s2_dirty), the fork happens only
     // after other work was queued on `stream` (st_ahead) or when an outside producer uses the stream (always_sync)
@@ -718,6 +720,46 @@ void* icsp_host_alloc(size_t bytes)
 
 void icsp_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
+// Uploads of all contexts of a device on one stream, downloads on another.  A stream's transfers go to the DMA engine its
+// first copy was given -- the lowest-numbered one idle at that moment, chosen among the engines of that copy's direction -- so
+// the streams of contexts set up one after the other all sit on ONE engine and every transfer of the device, up or down, runs
+// alone (icsp_enc, 3 workers, 3000 CIF frames: 18.6 ms = 1042 MB at the one-way rate).  A stream that only ever uploads and one
+// that only ever downloads sit on two engines whatever the order of events, and the link runs both ways at once
+// (tools/probe_duplex.hip: 17.0 -> 11.1 ms for 456 MB each way).
+int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
+{
+    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    HIPCHK(hipSetDevice(ctx->device));
+    join_s2(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!shared) { ctx->up_stream = ctx->down_stream = nullptr; return ICSP_OK; }
+    static std::mutex m;
+    static hipStream_t up[64], down[64];
+    std::lock_guard<std::mutex> l(m);
+    const int d = ctx->device & 63;
+    if (!up[d]) {
+        hipStream_t a = nullptr, b = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
+        // first-use costs of the two streams (a transfer queue each: milliseconds inside the first hipMemcpyAsync)
+        void* h = nullptr;
+        const size_t nb = std::min<size_t>((size_t)4 << 20, (size_t)((long long)ctx->max_frames * ctx->g.fsz));
+        if (hipHostMalloc(&h, nb, hipHostMallocDefault) == hipSuccess) {
+            memset(h, 0, nb);
+            (void)hipMemcpyAsync(ctx->d_frames, h, nb, hipMemcpyHostToDevice, a);
+            (void)hipStreamSynchronize(a);
+            (void)hipMemcpyAsync(h, ctx->d_frames, nb, hipMemcpyDeviceToHost, b);
+            (void)hipStreamSynchronize(b);
+            (void)hipHostFree(h);
+        } else (void)hipGetLastError();
+        up[d] = a; down[d] = b;
+    }
+    if (!ctx->ev_c1) HIPCHK(hipEventCreateWithFlags(&ctx->ev_c1, hipEventDisableTiming));
+    if (!ctx->ev_c2) HIPCHK(hipEventCreateWithFlags(&ctx->ev_c2, hipEventDisableTiming));
+    ctx->up_stream = up[d]; ctx->down_stream = down[d];
+    return ICSP_OK;
+}
+
 int icsp_host_register(void* p, size_t bytes, int read_only)
 {
     if (!p || !bytes) return ICSP_ERR_UNENOUGH_PARAM;
@@ -773,6 +815,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(&ctx->b, 0, sizeof(ctx->b));
     memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0; ctx->pk_host = nullptr; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
+    ctx->up_stream = nullptr; ctx->down_stream = nullptr; ctx->ev_c1 = nullptr; ctx->ev_c2 = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
     ctx->p_dirty = false; ctx->last_first = -1; ctx->last_n = -1;
     int no_fuse = 0;
@@ -856,12 +899,47 @@ int icsp_destroy(icsp_ctx_t* ctx)
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     for (int k = 0; k < kMaxPGroups; k++) if (ctx->ev_p1[k]) hipEventDestroy(ctx->ev_p1[k]);
+    if (ctx->ev_c1) hipEventDestroy(ctx->ev_c1);
+    if (ctx->ev_c2) hipEventDestroy(ctx->ev_c2);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) hipEventDestroy(ctx->ev_pjoin[k]); if (ctx->pstream[k]) hipStreamDestroy(ctx->pstream[k]); }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return ICSP_OK;
 }
+
+namespace {
+// Transfers of a context that uses the device's shared transfer streams (icsp_copy_streams): uploads run on one stream,
+// downloads on another, each ordered against the context's own stream by events.
+int copy_up(icsp_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    hipStream_t st = ctx->stream, up = ctx->up_stream;
+    if (!up) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return 0; }
+    HIPCHK(hipEventRecord(ctx->ev_c1, st));                        // after whatever still reads the destination
+    HIPCHK(hipStreamWaitEvent(up, ctx->ev_c1, 0));
+    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, up));
+    HIPCHK(hipEventRecord(ctx->ev_c2, up));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_c2, 0));
+    return 0;
+}
+// downloads: begin (the download stream waits for the context's stream), any number of copies on down_of(ctx), end (the host
+// waits for them -- and with them for everything queued on the context's stream before begin)
+hipStream_t down_of(icsp_ctx* ctx) { return ctx->down_stream ? ctx->down_stream : ctx->stream; }
+int copy_down_begin(icsp_ctx* ctx)
+{
+    if (!ctx->down_stream) return 0;
+    HIPCHK(hipEventRecord(ctx->ev_c1, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->down_stream, ctx->ev_c1, 0));
+    return 0;
+}
+int copy_down_end(icsp_ctx* ctx)
+{
+    if (!ctx->down_stream) { HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
+    HIPCHK(hipEventRecord(ctx->ev_c2, ctx->down_stream));
+    HIPCHK(hipEventSynchronize(ctx->ev_c2));
+    return 0;
+}
+} // namespace
 
 int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
 {
@@ -870,7 +948,7 @@ int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
     HIPCHK(hipSetDevice(ctx->device));
     join_s2(ctx);                                      // chroma kernels of an earlier encode may still read the frames
     ctx->st_ahead = true;
-    HIPCHK(hipMemcpyAsync(ctx->d_frames + (size_t)first * ctx->g.fsz, yuv, (size_t)n * ctx->g.fsz, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = copy_up(ctx, ctx->d_frames + (size_t)first * ctx->g.fsz, yuv, (size_t)n * ctx->g.fsz)) return rc;
     return ICSP_OK;
 }
 
@@ -899,14 +977,15 @@ int icsp_download(icsp_ctx_t* ctx, int first, int n, int16_t* levels, uint8_t* a
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nmb = ctx->g.nmb, f = first, c = n;
-    hipStream_t st = ctx->stream;
     join_s2(ctx);
+    if (int rc = copy_down_begin(ctx)) return rc;
+    hipStream_t st = down_of(ctx);
     if (levels) HIPCHK(hipMemcpyAsync(levels, ctx->b.levels + f * nmb * 384, c * nmb * 384 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
     if (acflag) HIPCHK(hipMemcpyAsync(acflag, ctx->b.acflag + f * nmb * 6, c * nmb * 6, hipMemcpyDeviceToHost, st));
     if (mpm) HIPCHK(hipMemcpyAsync(mpm, ctx->b.mpm + f * nmb * 4, c * nmb * 4, hipMemcpyDeviceToHost, st));
     if (mvd) HIPCHK(hipMemcpyAsync(mvd, ctx->b.mvd + f * nmb * 2, c * nmb * 2, hipMemcpyDeviceToHost, st));
     if (recon) HIPCHK(hipMemcpyAsync(recon, ctx->b.recon + f * ctx->g.fsz, c * ctx->g.fsz, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (int rc = copy_down_end(ctx)) return rc;
     if (ctx->profiling) collect_profile(ctx);
     return ICSP_OK;
 }
@@ -1063,7 +1142,8 @@ int icsp_pack_into(icsp_ctx_t* ctx, int first, int n, uint64_t at_bit, uint8_t* 
     uint8_t* dst = body_image + b0;
     const size_t A = (size_t)((uintptr_t)dst & 63);
     if (int rc = pack_write(ctx, first, n, (unsigned)(A * 8 + sh))) return rc;
-    hipStream_t st = ctx->stream;
+    if (int rc = copy_down_begin(ctx)) return rc;
+    hipStream_t st = down_of(ctx);
     const uint8_t* out = (const uint8_t*)ctx->pk.out;              // device byte A + j  <->  dst[j]
     const size_t lo = A, hi = A + nb;
     size_t ilo = (lo + 1 + 63) & ~(size_t)63, ihi = (hi - 1) & ~(size_t)63;      // aligned interior, first and last byte excluded
@@ -1074,7 +1154,7 @@ int icsp_pack_into(icsp_ctx_t* ctx, int first, int n, uint64_t at_bit, uint8_t* 
     if (ihi > ilo) HIPCHK(hipMemcpyAsync(dst + (ilo - lo), out + ilo, ihi - ilo, hipMemcpyDeviceToHost, st));
     if (nhead) HIPCHK(hipMemcpyAsync(head, out + lo, nhead, hipMemcpyDeviceToHost, st));
     if (ntail) HIPCHK(hipMemcpyAsync(tail, out + hi - ntail, ntail, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    if (int rc = copy_down_end(ctx)) return rc;
     for (size_t j = 0; j < nhead; j++) {
         if (j == 0 || j == nb - 1) __atomic_fetch_or(&dst[j], head[j], __ATOMIC_RELAXED);
         else dst[j] = head[j];

@@ -14,7 +14,8 @@
 // Streaming layout (load -> encode -> write of the reference, ENC:247-283 / 217-245 / 6376-6421, as a pipeline): the clip is
 // a queue of chunks of whole closed GOPs; workers -- a host thread and a context each -- take chunks in order and move them
 // through the device:  H2D -> kernels -> device bit packer -> D2H (bits + reconstruction).  The workers are at different
-// phases, so one's transfers overlap with another's kernels.
+// phases, so one's transfers overlap with another's kernels; the workers of a device upload in turn on one stream of the
+// device and download on another (icsp_copy_streams), so that one's upload runs under another's download.
 //   * Mapped mode (default): the input file and test_yuv.yuv are mmap'ed and the mappings pinned (icsp_host_register), so the
 //     uploads read the page cache and the downloads write it by DMA -- the host copies nothing.  A helper thread maps the
 //     files and allocates the output's pages (MAP_POPULATE: the slowest host step, ~6 GB/s on tmpfs whatever the thread
@@ -28,7 +29,7 @@
 //   --hostpack      sequential bit writer on the host instead of the device packer (same bytes; for cross-checks)
 //   --gpus N        devices to spread the workers over (default 1); --EnMultiThread N asks for N workers (the reference's N threads)
 //   --streams S     workers (contexts + host threads) per device when --EnMultiThread is not given (default: one per
-//                   chunk, at most 3)
+//                   chunk, at most 2)
 //   --chunk F       frames per chunk (rounded up to whole GOPs; default: 512 CIF frames' worth of macroblocks)
 //   --staged        staging buffers instead of pinned file mappings
 //   --nopin         the files are mapped but not pinned, as when the runtime refuses the ranges (tests the fall-back: staging
@@ -297,10 +298,10 @@ int main(int argc, char* argv[])
     int nworker;
     if (opt.multi_thread_mode > 0) nworker = opt.nthreads;
     else {
-        // default: up to three workers per device (measured on 3000 CIF frames: 1 worker 80 k, 2 workers 105 k, 3 workers
-        // 120 k frames/s; more add set-up time and nothing else), one per chunk on short clips
+        // default: up to two workers per device, one per chunk on short clips (3000 CIF frames, transfers on the device's shared
+        // up and down streams: 1 worker 115-119 k frames/s, 2 workers 170-185 k, 3, 4 and 6 the same with more set-up time)
         const int chunks_per_dev = (ngop + chunk_gops * std::max(1, opt.gpus) - 1) / (chunk_gops * std::max(1, opt.gpus));
-        const int per_dev = opt.streams > 0 ? opt.streams : std::max(1, std::min(3, chunks_per_dev));
+        const int per_dev = opt.streams > 0 ? opt.streams : std::max(1, std::min(2, chunks_per_dev));
         nworker = (opt.gpus > 0 ? opt.gpus : 1) * per_dev;
     }
     nworker = std::max(1, std::min({ nworker, ngop, 64 }));
@@ -330,11 +331,19 @@ int main(int argc, char* argv[])
     Barrier ready; ready.total = nworker;
     Cursor cursor;
     std::atomic<int> next_chunk(0);
+    // Several workers on a device: their uploads go through one stream of the device and their downloads through another
+    // (icsp_copy_streams), so that the link carries both directions at once -- on their own streams all transfers of the device
+    // end up on one DMA engine and run one at a time (3000 CIF frames: 18.6 ms = 1042 MB at the one-way rate; now 14-15 ms).
+    // And they upload in turn (whole chunks, each at the full rate, the first worker encoding while the second uploads)
+    // instead of all at once at a third of the rate each.
+    const bool shared_copies = nworker > ndev;
+    std::vector<std::mutex> up_turn(ndev);
     auto work = [&](Worker* w) {
         double t0 = now();
         const int cmax = std::min(chunk, n);
         w->rc = icsp_create(&w->ctx, &params, w->device, cmax);
         if (!w->rc) w->rc = icsp_prepare(w->ctx);
+        if (!w->rc && shared_copies) w->rc = icsp_copy_streams(w->ctx, 1);
         if (w->rc) w->err = std::string(icsp_strerror(w->rc)) + ": " + (w->ctx ? icsp_last_error(w->ctx) : "");
         maps_settled.wait();
         // pinned staging (each allocation costs milliseconds) only for whichever side is not mapped
@@ -405,7 +414,8 @@ int main(int argc, char* argv[])
                 if (rc) { fail(rc, nullptr); return; }
             } else {
                 t0 = now();
-                rc = icsp_upload(w->ctx, src, 0, cn);
+                if (shared_copies) { std::lock_guard<std::mutex> l(up_turn[w->device]); rc = icsp_upload(w->ctx, src, 0, cn); if (!rc) rc = icsp_sync(w->ctx); }
+                else rc = icsp_upload(w->ctx, src, 0, cn);
                 w->t_up += now() - t0; t0 = now();
                 if (!rc) rc = icsp_encode_resident(w->ctx, 0, cn);
                 w->t_enc += now() - t0; t0 = now();

@@ -177,6 +177,13 @@ int icsp_host_unregister(void* p);
  * ranges that must start out zeroed anyway, i.e. the body image icsp_pack_into fills (a stream's first large transfer into a
  * newly pinned range can cost the call about 6 ms). */
 int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes);
+/* Several contexts on one device: a stream's transfers go to the DMA engine the runtime gave its FIRST copy -- the lowest-
+ * numbered engine idle at that moment -- so contexts set up one after the other on an idle device all share one engine, and
+ * their transfers, uploads and downloads alike, then run one at a time (tools/probe_duplex.hip).
+ * shared != 0: the context's uploads (icsp_upload) run on one stream shared by all contexts of its device and its downloads
+ * (icsp_download, icsp_pack_into) on another, ordered against the context's own work by events, so that the link carries
+ * both directions at once; 0: transfers on the context's own stream again (the default). */
+int icsp_copy_streams(icsp_ctx_t* ctx, int shared);
 
 /* ---- decoder side: DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp ---- */
 /* Host: readHeader (DEC:14-37).  intra_period is the header field as stored: 1 (or 0) = every frame intra (DEC.h:293). */

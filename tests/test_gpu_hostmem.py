@@ -69,3 +69,59 @@ def test_host_warm_writes_zeros_only_and_keeps_a_count_from_leaking():
     assert wbits == bits and np.array_equal(image[: len(want)], want)
     assert capi.host_unregister(buf)
     enc.close()
+
+
+def test_shared_transfer_streams_from_two_threads():
+    """icsp_copy_streams: two contexts on one device, a host thread each, uploads on the device's shared upload stream and
+    downloads (reconstruction, bit strings, syntax arrays) on its shared download stream, chunk after chunk -- the same bytes as
+    one context on its own stream; switching back to the own stream works too."""
+    import threading
+    n, q, period, cn = 48, 8, 6, 12
+    clip = clipgen.synth_clip("stefanlike", n)
+    ref = capi.Encoder(W, H, q, q, period, max_frames=n)
+    want = ref.encode(clip)
+    want_bin = ref.pack_bitstream(0, n)
+    ref.close()
+    got = {k: np.zeros_like(v) for k, v in want.items()}
+    bits, strings = {}, {}
+    errs = []
+
+    def work(widx):
+        try:
+            enc = capi.Encoder(W, H, q, q, period, max_frames=cn)
+            enc.prepare()
+            enc.copy_streams(True)
+            for c in range(widx, n // cn, 2):
+                a = c * cn
+                enc.upload(clip[a:a + cn], 0)
+                enc.encode_resident(0, cn)
+                b = enc.pack_count(0, cn)
+                img = np.zeros((b + 7) // 8 + 64, np.uint8)
+                enc.pack_into(0, cn, 3, img)                       # at bit 3: head and tail bytes through the scratch
+                o = enc.download(0, cn)
+                for k in got:
+                    got[k][a:a + cn] = o[k]
+                bits[c], strings[c] = b, img
+                if c == 1:
+                    enc.copy_streams(False)                        # the rest of this worker's chunks on its own stream
+            enc.close()
+        except Exception as e:           # noqa: BLE001
+            errs.append((widx, repr(e)))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    # the chunks' strings, each packed at bit 3 of its own image, put together at their offsets == the whole body
+    body = np.zeros(len(want_bin) + 64, np.uint8)
+    at = 0
+    for c in range(n // cn):
+        s = np.unpackbits(strings[c])[3:3 + bits[c]]
+        tgt = np.unpackbits(body)
+        tgt[at:at + bits[c]] |= s
+        body = np.packbits(tgt)
+        at += bits[c]
+    assert capi.finish_image(W, H, q, q, period, np.concatenate([np.zeros(14, np.uint8), body]), at) == want_bin
