@@ -314,7 +314,17 @@ int main(int argc, char* argv[])
     chunk_gops = std::max(1, std::min(chunk_gops, (ngop + nworker - 1) / nworker));     // every worker gets something to do
     const int chunk = chunk_gops * L;
     std::vector<Chunk> chunks;
-    for (int f = 0; f < n; f += chunk) { Chunk c; c.first = f; c.count = std::min(chunk, n - f); c.bits = c.at = 0; c.direct = false; chunks.push_back(std::move(c)); }
+    // The download side carries more than the upload side (reconstruction + bits) and sets the pace; it can start when the
+    // first chunk has been uploaded, encoded and counted.  So with three chunks or more the first chunk of every device is a
+    // quarter and the second a half of the rest (3000 CIF frames all-intra: 14.7 -> 14.3 ms).
+    const bool ramp = ngop >= 3 * chunk_gops * ndev && chunk_gops >= 4;
+    for (int f = 0, k = 0; f < n; k++) {
+        int g = chunk_gops;
+        if (ramp && k < ndev) g = chunk_gops / 4; else if (ramp && k < 2 * ndev) g = chunk_gops / 2;
+        Chunk c; c.first = f; c.count = std::min(g * L, n - f); c.bits = c.at = 0; c.direct = false;
+        f += c.count;
+        chunks.push_back(std::move(c));
+    }
     const int nchunks = (int)chunks.size();
     std::vector<Worker> workers(nworker);
     for (int d = 0; d < nworker; d++) {

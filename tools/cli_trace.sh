@@ -15,7 +15,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd "$T"
 export TMPDIR=/tmp
 for g in 1; do
-timeout 120 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/g$g --output-format csv -- $GRAFT_REPO_ROOT/icspcodec_amd/icsp_enc -i "long_cif(352X288)_3000f.yuv" -n 3000 -q 16 --intraPeriod 0 --stats > $OUT/g$g.log 2>&1 || echo "rc $?"
+timeout 120 rocprofv3 --kernel-trace --memory-copy-trace -d $OUT/g$g --output-format csv -- $GRAFT_REPO_ROOT/icspcodec_amd/icsp_enc -i "long_cif(352X288)_3000f.yuv" -n 3000 -q 16 --intraPeriod ${PERIOD:-0} --stats > $OUT/g$g.log 2>&1 || echo "rc $?"
 tail -1 $OUT/g$g.log | cut -c1-400
 done
 cd $GRAFT_REPO_ROOT
