@@ -21,7 +21,7 @@ SYMBOLS = [
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
     "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
-    "icsp_bitstream_begin", "icsp_bitstream_header", "icsp_pack_count", "icsp_pack_into", "icsp_prepare", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free", "icsp_host_register", "icsp_host_unregister", "icsp_host_warm", "icsp_copy_streams",
+    "icsp_bitstream_begin", "icsp_bitstream_header", "icsp_pack_count", "icsp_pack_into", "icsp_prepare", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free", "icsp_host_register", "icsp_host_unregister", "icsp_host_warm", "icsp_copy_streams", "icsp_upload_sync",
 ]
 KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode"]
 
@@ -81,6 +81,7 @@ def load() -> C.CDLL:
         lib.icsp_host_unregister.argtypes = [vp]
         lib.icsp_host_warm.argtypes = [vp, vp, C.c_size_t]
         lib.icsp_copy_streams.argtypes = [vp, C.c_int]
+        lib.icsp_upload_sync.argtypes = [vp, vp, C.c_int, C.c_int]
         lib.icsp_bitstream_assemble.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(vp), C.POINTER(C.c_uint64), vp, C.c_size_t,
                                                 C.POINTER(C.c_size_t)]
         lib.icsp_parse_header.argtypes = [vp, C.c_size_t, C.POINTER(Params)]
@@ -292,6 +293,11 @@ class Encoder:
 
     def prepare(self):
         self._chk(self.lib.icsp_prepare(self.ctx), "icsp_prepare")
+
+    def upload_sync(self, frames: np.ndarray, first=0):
+        """Upload on the device's shared upload stream, back when the frames are there (icsp_upload_sync)."""
+        frames = np.ascontiguousarray(frames, np.uint8)
+        self._chk(self.lib.icsp_upload_sync(self.ctx, _vp(frames), first, frames.shape[0]), "icsp_upload_sync")
 
     def copy_streams(self, shared=True):
         """Uploads and downloads on the device's two shared transfer streams (icsp_copy_streams)."""

@@ -952,6 +952,20 @@ int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
     return ICSP_OK;
 }
 
+// Upload on the device's shared upload stream, returning when the frames are on the device.  It reads the context (device,
+// frame buffer, geometry, the shared stream) and changes nothing in it, so another host thread may run it while the
+// context's own thread packs and downloads an earlier batch -- see icsp_hip.h for what the caller has to guarantee.
+int icsp_upload_sync(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
+{
+    if (!ctx || !yuv) return ICSP_ERR_UNENOUGH_PARAM;
+    if (int rc = check_range(ctx, first, n)) return rc;
+    if (!ctx->up_stream) return ICSP_ERR_UNCORRECT_PARAM;
+    if (hipSetDevice(ctx->device) != hipSuccess) return ICSP_ERR_HIP;
+    if (hipMemcpyAsync(ctx->d_frames + (size_t)first * ctx->g.fsz, yuv, (size_t)n * ctx->g.fsz, hipMemcpyHostToDevice, ctx->up_stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->up_stream) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
+    return ICSP_OK;
+}
+
 int icsp_encode_resident(icsp_ctx_t* ctx, int first, int n)
 {
     if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;

@@ -14,7 +14,7 @@
 // Streaming layout (load -> encode -> write of the reference, ENC:247-283 / 217-245 / 6376-6421, as a pipeline): the clip is
 // a queue of chunks of whole closed GOPs; workers -- a host thread and a context each -- take chunks in order and move them
 // through the device:  H2D -> kernels -> device bit packer -> D2H (bits + reconstruction).  The workers are at different
-// phases, so one's transfers overlap with another's kernels; the workers of a device upload in turn on one stream of the
+// phases, so one's transfers overlap with another's kernels; the uploads of a device are made by one thread on one stream of the
 // device and download on another (icsp_copy_streams), so that one's upload runs under another's download.
 //   * Mapped mode (default): the input file and test_yuv.yuv are mmap'ed and the mappings pinned (icsp_host_register), so the
 //     uploads read the page cache and the downloads write it by DMA -- the host copies nothing.  A helper thread maps the
@@ -53,6 +53,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -157,6 +158,8 @@ struct Worker {
     icsp_ctx_t* ctx;
     uint8_t* body; size_t body_cap;                        // pinned: one chunk's bit string, when it cannot go direct
     uint8_t* stage;                                        // pinned staging for frames / reconstruction (staged mode only)
+    uint8_t* stage_in;                                     //   its input half (null when the input file is mapped and pinned)
+    int up_chunk, up_rc; bool up_done;                     // the upload this worker has handed to its device's uploader thread
     double t_setup, t_read, t_write, t_up, t_enc, t_count, t_turn, t_pack, t_down;
 };
 
@@ -329,7 +332,7 @@ int main(int argc, char* argv[])
     std::vector<Worker> workers(nworker);
     for (int d = 0; d < nworker; d++) {
         Worker& w = workers[d];
-        w.device = d % ndev; w.rc = 0; w.chunks = 0; w.ctx = nullptr; w.body = nullptr; w.body_cap = 0; w.stage = nullptr;
+        w.device = d % ndev; w.rc = 0; w.chunks = 0; w.ctx = nullptr; w.body = nullptr; w.body_cap = 0; w.stage = nullptr; w.stage_in = nullptr; w.up_chunk = -1; w.up_rc = 0; w.up_done = true;
         w.t_setup = w.t_read = w.t_write = w.t_up = w.t_enc = w.t_count = w.t_turn = w.t_pack = w.t_down = 0;
     }
 
@@ -347,7 +350,31 @@ int main(int argc, char* argv[])
     // And they upload in turn (whole chunks, each at the full rate, the first worker encoding while the second uploads)
     // instead of all at once at a third of the rate each.
     const bool shared_copies = nworker > ndev;
-    std::vector<std::mutex> up_turn(ndev);
+    // One uploader thread per device makes all uploads of that device, one at a time (icsp_upload_sync): each runs at the
+    // full rate, and none is submitted while the upload stream's DMA engine is busy -- a copy submitted then is given another
+    // engine, whose first use costs milliseconds (3000 frames: 15 ms became 21-30 ms, varying from run to run).  A worker
+    // hands over its NEXT chunk as soon as the current one is encoded (the frames are no longer needed; icsp_pack_count has
+    // waited for the kernels), so the upload runs beside the packing and the downloads of the current chunk.
+    struct Uploader { std::mutex m; std::condition_variable cv; std::deque<Worker*> q; bool stop = false; };
+    std::vector<Uploader> uploaders(shared_copies ? ndev : 0);
+    auto uploader_loop = [&](Uploader* u) {
+        for (;;) {
+            Worker* w;
+            {
+                std::unique_lock<std::mutex> l(u->m);
+                u->cv.wait(l, [&] { return u->stop || !u->q.empty(); });
+                if (u->q.empty()) return;
+                w = u->q.front(); u->q.pop_front();
+            }
+            const Chunk& ch = chunks[w->up_chunk];
+            const size_t f = (size_t)ch.first, bytes = fsz * ch.count;
+            int rc = 0;
+            if (w->stage_in && !pread_all(fd_in, w->stage_in, bytes, (off_t)(f * fsz))) rc = ICSP_ERR_RANGE;
+            if (!rc) rc = icsp_upload_sync(w->ctx, w->stage_in ? w->stage_in : in_map + f * fsz, 0, ch.count);
+            { std::lock_guard<std::mutex> l(u->m); w->up_rc = rc; w->up_done = true; }
+            u->cv.notify_all();
+        }
+    };
     auto work = [&](Worker* w) {
         double t0 = now();
         const int cmax = std::min(chunk, n);
@@ -364,6 +391,7 @@ int main(int argc, char* argv[])
             w->stage = (uint8_t*)icsp_host_alloc(cbytes * nstage);
             if (!w->stage) { w->rc = ICSP_ERR_MEM_ALLOC; w->err = "pinned host memory"; }
             stage_in = in_map ? nullptr : w->stage;
+            w->stage_in = stage_in;
             stage_out = out_map ? nullptr : w->stage + (in_map ? 0 : cbytes);
         }
         // a chunk's bit string that cannot go straight into the .bin mapping comes back through a pinned buffer: almost
@@ -406,33 +434,64 @@ int main(int argc, char* argv[])
             cursor.cv.notify_all();
         };
         if (w->rc) { fail(w->rc, w->err.c_str()); return; }
-        for (int c; (c = next_chunk.fetch_add(1)) < nchunks;) {
+        // shared transfer streams: hand chunk c to the device's uploader / wait for it; else read (staged mode) + upload here
+        auto post_upload = [&](int c) {
+            Uploader& u = uploaders[w->device];
+            { std::lock_guard<std::mutex> l(u.m); w->up_chunk = c; w->up_done = false; w->up_rc = 0; u.q.push_back(w); }
+            u.cv.notify_all();
+        };
+        auto wait_upload = [&]() -> int {
+            Uploader& u = uploaders[w->device];
+            const double t = now();
+            std::unique_lock<std::mutex> l(u.m);
+            u.cv.wait(l, [&] { return w->up_done; });
+            w->t_up += now() - t;
+            return w->up_rc;
+        };
+        auto upload_here = [&](int c) -> int {
+            const Chunk& ch = chunks[c];
+            const size_t f = (size_t)ch.first, bytes = fsz * ch.count;
+            double t = now();
+            if (!in_map && !pread_all(fd_in, stage_in, bytes, (off_t)(f * fsz))) return ICSP_ERR_RANGE;
+            w->t_read += now() - t; t = now();
+            const int rc = icsp_upload(w->ctx, in_map ? in_map + f * fsz : stage_in, 0, ch.count);
+            w->t_up += now() - t;
+            return rc;
+        };
+        const bool early = shared_copies && !opt.hostpack;
+        int c = next_chunk.fetch_add(1);
+        if (c < nchunks && !opt.hostpack) {
+            int rc;
+            if (early) { post_upload(c); rc = wait_upload(); } else rc = upload_here(c);
+            if (rc) { fail(rc, rc == ICSP_ERR_RANGE ? "short read" : nullptr); return; }
+        }
+        while (c < nchunks) {
             Chunk& ch = chunks[c];
             const int cn = ch.count;
             const size_t f = (size_t)ch.first, bytes = fsz * cn;
-            const uint8_t* src = in_map ? in_map + f * fsz : stage_in;
             uint8_t* rec = out_map ? out_map + f * fsz : stage_out;
-            t0 = now();
-            if (!in_map && !pread_all(fd_in, stage_in, bytes, (off_t)(f * fsz))) { fail(ICSP_ERR_RANGE, "short read"); return; }
-            w->t_read += now() - t0;
-            int rc;
+            int rc, c2;
             if (opt.hostpack) {
+                const uint8_t* src = in_map ? in_map + f * fsz : stage_in;
                 t0 = now();
+                if (!in_map && !pread_all(fd_in, stage_in, bytes, (off_t)(f * fsz))) { fail(ICSP_ERR_RANGE, "short read"); return; }
+                w->t_read += now() - t0; t0 = now();
                 rc = icsp_encode_gop(w->ctx, src, cn, levels.data() + f * nmb * 384, acflag.data() + f * nmb * 6,
                                      mpm.data() + f * nmb * 4, mvd.data() + f * nmb * 2, rec);
                 w->t_enc += now() - t0;
                 if (rc) { fail(rc, nullptr); return; }
+                c2 = next_chunk.fetch_add(1);
             } else {
                 t0 = now();
-                if (shared_copies) { std::lock_guard<std::mutex> l(up_turn[w->device]); rc = icsp_upload(w->ctx, src, 0, cn); if (!rc) rc = icsp_sync(w->ctx); }
-                else rc = icsp_upload(w->ctx, src, 0, cn);
-                w->t_up += now() - t0; t0 = now();
-                if (!rc) rc = icsp_encode_resident(w->ctx, 0, cn);
+                rc = icsp_encode_resident(w->ctx, 0, cn);
                 w->t_enc += now() - t0; t0 = now();
                 uint64_t bits = 0;
                 if (!rc) rc = icsp_pack_count(w->ctx, 0, cn, &bits);
-                w->t_count += now() - t0; t0 = now();
+                w->t_count += now() - t0;
                 if (rc) { fail(rc, nullptr); return; }
+                c2 = next_chunk.fetch_add(1);
+                if (early && c2 < nchunks) post_upload(c2);
+                t0 = now();
                 {   // my turn: every earlier chunk has reported its length
                     std::unique_lock<std::mutex> l(cursor.m);
                     cursor.cv.wait(l, [&] { return cursor.turn == c || cursor.failed; });
@@ -460,13 +519,21 @@ int main(int argc, char* argv[])
             if (!out_map && fd_rec >= 0) pwrite_all(fd_rec, stage_out, bytes, (off_t)(f * fsz));
             w->t_write += now() - t0;
             w->chunks++;
+            if (!opt.hostpack && c2 < nchunks) {
+                rc = early ? wait_upload() : upload_here(c2);
+                if (rc) { fail(rc, rc == ICSP_ERR_RANGE ? "short read" : nullptr); return; }
+            }
+            c = c2;
         }
     };
     {
-        std::vector<std::thread> th;
+        std::vector<std::thread> th, up;
+        for (auto& u : uploaders) up.emplace_back(uploader_loop, &u);
         for (int d = 1; d < nworker; d++) th.emplace_back(work, &workers[d]);
         work(&workers[0]);
         for (auto& t : th) t.join();
+        for (auto& u : uploaders) { { std::lock_guard<std::mutex> l(u.m); u.stop = true; } u.cv.notify_all(); }
+        for (auto& t : up) t.join();
     }
     helper.join();
     for (auto& w : workers)

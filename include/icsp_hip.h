@@ -184,6 +184,14 @@ int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes);
  * (icsp_download, icsp_pack_into) on another, ordered against the context's own work by events, so that the link carries
  * both directions at once; 0: transfers on the context's own stream again (the default). */
 int icsp_copy_streams(icsp_ctx_t* ctx, int shared);
+/* icsp_upload on the device's shared upload stream (icsp_copy_streams must be on), returning when the frames are on the
+ * device.  It changes nothing in the context, so a second host thread may call it while the context's own thread packs and
+ * downloads an earlier batch -- the one exception to "calls on one context must be serialised".  The caller guarantees that
+ * no kernel of the context that reads the frames is queued or running (the last encode has been waited for: icsp_pack_count,
+ * icsp_sync or a download has returned) and starts the next encode only after this call has returned.  A host that makes
+ * all uploads of a device from ONE thread this way, one at a time, also keeps them on one DMA engine: a copy submitted while
+ * the stream's engine is busy is given another engine, whose first use costs milliseconds. */
+int icsp_upload_sync(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n);
 
 /* ---- decoder side: DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp ---- */
 /* Host: readHeader (DEC:14-37).  intra_period is the header field as stored: 1 (or 0) = every frame intra (DEC.h:293). */

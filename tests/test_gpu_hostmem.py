@@ -125,3 +125,36 @@ def test_shared_transfer_streams_from_two_threads():
         body = np.packbits(tgt)
         at += bits[c]
     assert capi.finish_image(W, H, q, q, period, np.concatenate([np.zeros(14, np.uint8), body]), at) == want_bin
+
+
+def test_upload_sync_from_a_second_thread_beside_the_downloads():
+    """icsp_upload_sync: the next chunk's frames go up from another host thread while the context's own thread packs and
+    downloads the current chunk (icsp_enc's uploader thread); refused without the shared transfer streams."""
+    import threading
+    n, q, period, cn = 36, 16, 3, 9
+    clip = clipgen.synth_clip("mobilelike", n)
+    ref = capi.Encoder(W, H, q, q, period, max_frames=n)
+    want = ref.encode(clip)
+    ref.close()
+    enc = capi.Encoder(W, H, q, q, period, max_frames=cn)
+    with pytest.raises(RuntimeError):
+        enc.upload_sync(clip[:cn])
+    enc.copy_streams(True)
+    got = {k: np.zeros_like(v) for k, v in want.items()}
+    enc.upload_sync(clip[:cn])
+    for c in range(n // cn):
+        a = c * cn
+        enc.encode_resident(0, cn)
+        enc.pack_count(0, cn)                                  # the kernels are through: the frames may be overwritten
+        up = None
+        if c + 1 < n // cn:
+            up = threading.Thread(target=enc.upload_sync, args=(clip[a + cn:a + 2 * cn],))
+            up.start()
+        o = enc.download(0, cn)
+        for k in got:
+            got[k][a:a + cn] = o[k]
+        if up:
+            up.join()
+    enc.close()
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
