@@ -14,8 +14,9 @@
 // Streaming layout (load -> encode -> write of the reference, ENC:247-283 / 217-245 / 6376-6421, as a pipeline): the clip is
 // a queue of chunks of whole closed GOPs; workers -- a host thread and a context each -- take chunks in order and move them
 // through the device:  H2D -> kernels -> device bit packer -> D2H (bits + reconstruction).  The workers are at different
-// phases, so one's transfers overlap with another's kernels; the uploads of a device are made by one thread on one stream of the
-// device and download on another (icsp_copy_streams), so that one's upload runs under another's download.
+// phases, so one's transfers overlap with another's kernels; all uploads of a device are made by one uploader thread on one
+// stream of the device, all downloads run on another (icsp_copy_streams), and a worker's next chunk goes up while its
+// current one is packed and downloaded.
 //   * Mapped mode (default): the input file and test_yuv.yuv are mmap'ed and the mappings pinned (icsp_host_register), so the
 //     uploads read the page cache and the downloads write it by DMA -- the host copies nothing.  A helper thread maps the
 //     files and allocates the output's pages (MAP_POPULATE: the slowest host step, ~6 GB/s on tmpfs whatever the thread
