@@ -87,7 +87,7 @@ void print_help_message()
     printf("--intraPeriod: period of intra frame(0: All intra)\n");
     printf("--EnMultiThread: enable multi threading mode, also the number of thread(0~4, 0 is disable)\n");
     printf("--gpus : [MI355X build] number of GPUs to shard closed GOPs over (default 1)\n");
-    printf("--streams : [MI355X build] workers (host thread + context) per GPU (default up to 3)\n");
+    printf("--streams : [MI355X build] workers (host thread + context) per GPU (default up to 2)\n");
     printf("--chunk : [MI355X build] frames per chunk moved through the device (default 512 CIF frames' worth)\n");
     printf("--staged : [MI355X build] staging buffers instead of pinned mappings of the input and output files\n");
     printf("--hostpack : [MI355X build] pack the bitstream on the host instead of on the device (same bytes)\n");
