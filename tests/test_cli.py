@@ -57,6 +57,29 @@ def test_cli_outputs_equal_reference_files(tmp_path, golden_dir, period, extra):
     assert hashlib.sha256((tmp_path / "test_yuv.yuv").read_bytes()).hexdigest() == ref["recon_sha256"]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,qp,period,extra", [("foremanlike", 16, 0, ["--chunk", "64"]), ("foremanlike", 16, 10, ["--chunk", "50"]),
+                                                  ("stefanlike", 8, 10, ["--chunk", "40", "--streams", "3"]),
+                                                  ("foremanlike", 16, 10, ["--chunk", "50", "--staged"]),
+                                                  ("foremanlike", 16, 0, ["--chunk", "64", "--streams", "1"])])
+def test_cli_300_frames_in_ramped_chunks(tmp_path, golden_dir, name, qp, period, extra):
+    """300 frames in many chunks: the first chunk a quarter and the second a half of the rest, two (or three) workers whose
+    uploads go through the device's uploader thread while they pack and download (one worker: on its own stream) ->
+    the reference's files."""
+    n = 300
+    clip = clipgen.synth_clip(name, n)
+    fn = clipgen.file_name(name, n)
+    clip.tofile(tmp_path / fn)
+    r = run(["-i", fn, "-n", str(n), "-q", str(qp), "--intraPeriod", str(period), "--stats"] + extra, tmp_path)
+    assert r.returncode == 0, r.stdout
+    st = json.loads(r.stdout.decode().split("[icsp_enc]", 1)[1])
+    assert st["chunks"] >= 6 and st["workers"] == (int(extra[extra.index("--streams") + 1]) if "--streams" in extra else 2)
+    streams = json.load(open(os.path.join(golden_dir, "streams.json")))
+    ref = [s for s in streams if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == (name, n, qp, period) and "bin_sha256" in s][0]
+    assert hashlib.sha256((tmp_path / f"{name}_compCIF_{qp}_{qp}_{period}.bin").read_bytes()).hexdigest() == ref["bin_sha256"]
+    assert hashlib.sha256((tmp_path / "test_yuv.yuv").read_bytes()).hexdigest() == ref["recon_sha256"]
+
+
 DEC = os.path.join(ROOT, "icspcodec_amd", "icsp_dec")
 
 
