@@ -181,8 +181,9 @@ int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes);
  * numbered engine idle at that moment -- so contexts set up one after the other on an idle device all share one engine, and
  * their transfers, uploads and downloads alike, then run one at a time (tools/probe_duplex.hip).
  * shared != 0: the context's uploads (icsp_upload) run on one stream shared by all contexts of its device and its downloads
- * (icsp_download, icsp_pack_into) on another, ordered against the context's own work by events, so that the link carries
- * both directions at once; 0: transfers on the context's own stream again (the default). */
+ * (icsp_download, icsp_pack_into) on another, so that the link carries both directions at once.  A transfer then starts when
+ * the context's own stream is idle and the call returns when it is complete (icsp_upload too), one at a time per direction
+ * and device; 0: transfers on the context's own stream again (the default). */
 int icsp_copy_streams(icsp_ctx_t* ctx, int shared);
 /* icsp_upload on the device's shared upload stream (icsp_copy_streams must be on), returning when the frames are on the
  * device.  It changes nothing in the context, so a second host thread may call it while the context's own thread packs and
