@@ -748,37 +748,41 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
         hipStream_t a = nullptr, b = nullptr;
         HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
         uint8_t* h = nullptr;
-        const size_t nb = std::min<size_t>((size_t)8 << 20, (size_t)((long long)ctx->max_frames * ctx->g.fsz));
+        const size_t nb = (size_t)8 << 20;
+        uint8_t* dv = nullptr;                                         // device scratch: nothing of the context is touched
         if (hipHostMalloc((void**)&h, 2 * nb, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h = nullptr; }
+        if (h && hipMalloc((void**)&dv, 2 * nb) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); h = nullptr; }
+        if (dv) (void)hipMemset(dv, 0, 2 * nb);
         auto seconds = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         if (h) {
             memset(h, 0, 2 * nb);
-            (void)hipMemcpyAsync(ctx->d_frames, h, nb, hipMemcpyHostToDevice, a);       // first use of the upload stream
+            (void)hipMemcpyAsync(dv, h, nb, hipMemcpyHostToDevice, a);       // first use of the upload stream
             (void)hipStreamSynchronize(a);
         }
         for (int attempt = 0; attempt < 4; attempt++) {
             HIPCHK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
             if (!h) break;
             const int busy = (int)std::min<size_t>(64, ((size_t)96 << 20) / nb);        // about 2 ms of uploads queued
-            for (int k = 0; k < busy; k++) (void)hipMemcpyAsync(ctx->d_frames, h, nb, hipMemcpyHostToDevice, a);
-            (void)hipMemcpyAsync(h + nb, ctx->b.recon, nb, hipMemcpyDeviceToHost, b);   // first use of the download stream, under them
+            for (int k = 0; k < busy; k++) (void)hipMemcpyAsync(dv, h, nb, hipMemcpyHostToDevice, a);
+            (void)hipMemcpyAsync(h + nb, dv + nb, nb, hipMemcpyDeviceToHost, b);   // first use of the download stream, under them
             (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
             double t_seq = 1e9, t_both = 1e9;
             for (int rep = 0; rep < 3; rep++) {
                 double t = seconds();
-                (void)hipMemcpyAsync(ctx->d_frames, h, nb, hipMemcpyHostToDevice, a); (void)hipStreamSynchronize(a);
-                (void)hipMemcpyAsync(h + nb, ctx->b.recon, nb, hipMemcpyDeviceToHost, b); (void)hipStreamSynchronize(b);
+                (void)hipMemcpyAsync(dv, h, nb, hipMemcpyHostToDevice, a); (void)hipStreamSynchronize(a);
+                (void)hipMemcpyAsync(h + nb, dv + nb, nb, hipMemcpyDeviceToHost, b); (void)hipStreamSynchronize(b);
                 t_seq = std::min(t_seq, seconds() - t);
                 t = seconds();
-                (void)hipMemcpyAsync(ctx->d_frames, h, nb, hipMemcpyHostToDevice, a);
-                (void)hipMemcpyAsync(h + nb, ctx->b.recon, nb, hipMemcpyDeviceToHost, b);
+                (void)hipMemcpyAsync(dv, h, nb, hipMemcpyHostToDevice, a);
+                (void)hipMemcpyAsync(h + nb, dv + nb, nb, hipMemcpyDeviceToHost, b);
                 (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
                 t_both = std::min(t_both, seconds() - t);
             }
-            if (nb < ((size_t)1 << 20) || t_both < 0.8 * t_seq) break;                  // (tiny contexts: nothing to measure)
+            if (t_both < 0.8 * t_seq) break;
             if (attempt < 3) { (void)hipStreamDestroy(b); b = nullptr; }
         }
         if (h) (void)hipHostFree(h);
+        if (dv) (void)hipFree(dv);
         (void)hipGetLastError();
         up[d] = a; down[d] = b;
     }
