@@ -14,6 +14,11 @@
 #include <thread>
 #include <vector>
 __global__ void k_touch(char* p) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] = (char)(p[0] + 1); }
+// device -> pinned host by a kernel instead of a DMA engine: 16 bytes per lane, grid-stride
+__global__ void k_copy_out(uint4* dst, const uint4* src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main(int argc, char** argv)
 {
@@ -143,6 +148,20 @@ int main(int argc, char** argv)
             printf("   3 workers, uploads take turns: %.1f ms\n", (now() - t) * 1e3);
         }
         for (auto& x : q) (void)hipStreamDestroy(x);
+    }
+    // downloads by a copy kernel, uploads by the DMA engine: can never share an engine
+    for (int wgs : {16, 32, 64, 128, 256}) for (int reg = 0; reg < 2; reg++) {
+        char* out = reg ? mo : hq; char* in = reg ? mi : hp;
+        for (int rep = 0; rep < 2; rep++) {
+            double t = now();
+            hipLaunchKernelGGL(k_copy_out, dim3(wgs), dim3(256), 0, s[1], (uint4*)out, (const uint4*)d1, N / 16); (void)hipStreamSynchronize(s[1]);
+            const double td = now() - t;
+            t = now();
+            (void)hipMemcpyAsync(d0, in, N, hipMemcpyHostToDevice, s[0]);
+            hipLaunchKernelGGL(k_copy_out, dim3(wgs), dim3(256), 0, s[1], (uint4*)out, (const uint4*)d1, N / 16);
+            (void)hipStreamSynchronize(s[0]); (void)hipStreamSynchronize(s[1]);
+            if (rep) printf("copy kernel D2H, %3d workgroups, %-20s: alone %.1f ms (%.1f GB/s), beside a DMA upload %.1f ms\n", wgs, reg ? "registered mappings" : "hipHostMalloc", td * 1e3, N / td / 1e9, (now() - t) * 1e3);
+        }
     }
     (void)hipHostUnregister(mi); (void)hipHostUnregister(mo); munmap(mi, N); munmap(mo, N); close(fi); close(fo);
     unlink(fin.c_str()); unlink(fout.c_str());
