@@ -310,7 +310,6 @@ struct icsp_ctx {
     hipStream_t stream, stream2;      // stream2: I-frame chroma beside the luma wavefront kernel (all-intra); all I-frame kernels (IPPP)
     hipEvent_t ev_fork, ev_join;
     hipStream_t up_stream, down_stream;   // icsp_copy_streams: the device's shared transfer streams (null: transfers on `stream`)
-    hipEvent_t ev_c1, ev_c2;
     // all-intra batches: stream2's chroma work and the luma kernel touch disjoint data, so consecutive encodes need no
     // cross-stream events at all; the join is deferred until something reads results (s2_dirty), the fork happens only
     // after other work was queued on `stream` (st_ahead) or when an outside producer uses the stream (always_sync)
@@ -786,8 +785,6 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
         (void)hipGetLastError();
         up[d] = a; down[d] = b;
     }
-    if (!ctx->ev_c1) HIPCHK(hipEventCreateWithFlags(&ctx->ev_c1, hipEventDisableTiming));
-    if (!ctx->ev_c2) HIPCHK(hipEventCreateWithFlags(&ctx->ev_c2, hipEventDisableTiming));
     ctx->up_stream = up[d]; ctx->down_stream = down[d];
     return ICSP_OK;
 }
@@ -847,7 +844,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(&ctx->b, 0, sizeof(ctx->b));
     memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0; ctx->pk_host = nullptr; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
-    ctx->up_stream = nullptr; ctx->down_stream = nullptr; ctx->ev_c1 = nullptr; ctx->ev_c2 = nullptr;
+    ctx->up_stream = nullptr; ctx->down_stream = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
     ctx->p_dirty = false; ctx->last_first = -1; ctx->last_n = -1;
     int no_fuse = 0;
@@ -931,8 +928,6 @@ int icsp_destroy(icsp_ctx_t* ctx)
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     for (int k = 0; k < kMaxPGroups; k++) if (ctx->ev_p1[k]) hipEventDestroy(ctx->ev_p1[k]);
-    if (ctx->ev_c1) hipEventDestroy(ctx->ev_c1);
-    if (ctx->ev_c2) hipEventDestroy(ctx->ev_c2);
     if (ctx->stream2) hipStreamDestroy(ctx->stream2);
     for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) hipEventDestroy(ctx->ev_pjoin[k]); if (ctx->pstream[k]) hipStreamDestroy(ctx->pstream[k]); }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -971,9 +966,7 @@ int copy_down_begin(icsp_ctx* ctx, DownTurn& turn)
 }
 int copy_down_end(icsp_ctx* ctx)
 {
-    if (!ctx->down_stream) { HIPCHK(hipStreamSynchronize(ctx->stream)); return 0; }
-    HIPCHK(hipEventRecord(ctx->ev_c2, ctx->down_stream));
-    HIPCHK(hipEventSynchronize(ctx->ev_c2));
+    HIPCHK(hipStreamSynchronize(down_of(ctx)));                   // (the shared stream carries this context's copies alone: the turn)
     return 0;
 }
 } // namespace
