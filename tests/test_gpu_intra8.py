@@ -36,6 +36,7 @@ def form8():
     ("mobilelike", 3, 16, 1, 3, 352, 288), ("staticlike", 4, 1, 1, 4, 352, 288), ("tablelike", 3, 8, 8, 0, 64, 48),
     ("newslike", 2, 16, 16, 0, 32, 16), ("stefanlike", 3, 8, 8, 3, 416, 240), ("mobilelike", 2, 8, 8, 0, 704, 576),
     ("tablelike", 3, 16, 16, 3, 1920, 1088), ("mobilelike", 2, 16, 16, 2, 2048, 1088),
+    ("mobilelike", 2, 16, 16, 2, 32, 2304), ("tablelike", 2, 8, 8, 0, 4096, 32), ("stefanlike", 2, 1, 1, 0, 48, 1600),
 ])
 def test_forced_8_lane_form_matches_oracle(form8, name, n, qdc, qac, period, w, h):
     clip = clipgen.synth_clip(name, n, width=w, height=h)

@@ -191,6 +191,26 @@ def test_largest_supported_frame_2048x1088():
     assert np.array_equal(dec, po.decode_sequence(want["levels"], want["mpm"], want["mvd"], w, h, 16, 16, 2))
 
 
+@pytest.mark.parametrize("w,h,period,q", [(4096, 16, 2, 16), (4096, 32, 0, 8), (4096, 32, 3, 1), (4096, 528, 2, 16),
+                                          (32, 2304, 2, 16), (32, 2304, 0, 1), (48, 1600, 3, 8), (64, 2176, 2, 16)])
+def test_extreme_aspect_ratios(w, h, period, q):
+    """The widest frame the interface takes (4096: 512 blocks on a row, one to 33 macroblock rows) and the tallest (2304 lines:
+    288 block rows, the DC chains in five bands of 64 rows; motion search with two macroblock columns).  Encode (forced 8-lane
+    form as well where the frame is all-intra), device packer, decode."""
+    n = 3
+    clip = clipgen.synth_clip("mobilelike", n, width=w, height=h)
+    want = po.encode_sequence(clip, w, h, q, q, period, nthreads=4)
+    enc = capi.Encoder(w, h, q, q, period, max_frames=n)
+    got = enc.encode(clip)
+    bs = enc.pack_bitstream(0, n)
+    enc.decode_resident(0, n)
+    dec = enc.download(0, n, what=("recon",))["recon"]
+    enc.close()
+    _cmp(got, want, f"{w}x{h} p={period} q={q}: ")
+    assert bs == capi.write_bitstream(w, h, q, q, period, want["levels"], want["acflag"], want["mpm"], want["mvd"])
+    assert np.array_equal(dec, po.decode_sequence(want["levels"], want["mpm"], want["mvd"], w, h, q, q, period))
+
+
 def test_4cif_all_intra_and_size_limit():
     w, h = 704, 576
     clip = clipgen.synth_clip("mobilelike", 2, width=w, height=h)
