@@ -4,6 +4,7 @@ import json
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
 from icspcodec_amd import clipgen
@@ -78,6 +79,26 @@ def test_cli_300_frames_in_ramped_chunks(tmp_path, golden_dir, name, qp, period,
     ref = [s for s in streams if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == (name, n, qp, period) and "bin_sha256" in s][0]
     assert hashlib.sha256((tmp_path / f"{name}_compCIF_{qp}_{qp}_{period}.bin").read_bytes()).hexdigest() == ref["bin_sha256"]
     assert hashlib.sha256((tmp_path / "test_yuv.yuv").read_bytes()).hexdigest() == ref["recon_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,n,period,extra", [(704, 576, 6, 3, []), (64, 48, 40, 4, ["--chunk", "8", "--streams", "2"]),
+                                                (1920, 1088, 4, 2, ["--chunk", "2"]), (32, 16, 9, 0, ["--staged"])])
+def test_cli_other_frame_sizes(tmp_path, w, h, n, period, extra):
+    """--width / --height (the reference hard-codes 352x288, encoder_main.cpp:20): the files equal what the oracle and the host
+    bit writer give for that geometry."""
+    from oracle import pyoracle as po
+    from icspcodec_amd import capi
+    qp = 16
+    clip = clipgen.synth_clip("mobilelike", n, width=w, height=h)
+    fn = f"mobilelike_x({w}X{h})_{n}f.yuv"
+    clip.tofile(tmp_path / fn)
+    r = run(["-i", fn, "-n", str(n), "-q", str(qp), "--intraPeriod", str(period), "--width", str(w), "--height", str(h)] + extra, tmp_path)
+    assert r.returncode == 0, r.stdout
+    want = po.encode_sequence(clip, w, h, qp, qp, period, nthreads=4)
+    bs = capi.write_bitstream(w, h, qp, qp, period, want["levels"], want["acflag"], want["mpm"], want["mvd"])
+    assert (tmp_path / f"mobilelike_compCIF_{qp}_{qp}_{period}.bin").read_bytes() == bs
+    assert np.array_equal(np.fromfile(tmp_path / "test_yuv.yuv", np.uint8), want["recon"].reshape(-1))
 
 
 DEC = os.path.join(ROOT, "icspcodec_amd", "icsp_dec")
