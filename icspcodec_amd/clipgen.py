@@ -163,3 +163,28 @@ def psnr_y(orig: np.ndarray, recon: np.ndarray, width: int, height: int) -> floa
     mse = ((o - r) ** 2).mean(axis=1)
     mse = np.maximum(mse, 1e-12)
     return float((20.0 * np.log10(255.0 / np.sqrt(mse))).mean())
+
+
+def hashed_clip(kind: str, seed: int, nframes: int, width: int, height: int) -> np.ndarray:
+    """Deterministic stress content for any geometry (integer hash only, like synth_clip): ``noise`` (uniform bytes),
+    ``extremes`` (every byte 0 or 255), ``flat`` (one value), ``gradient`` (ramps), ``repeat`` (identical noisy frames:
+    zero SADs, the early break and the carried search state of motionEstimation,
+    ICSP_Codec_Encoder_source.cpp:2095, 2136-2141).  Used by the geometry fixtures (tools/make_golden.py), whose expected
+    outputs come from the compiled reference, so the bytes must be the same on every box."""
+    fsz = width * height * 3 // 2
+    rows = (fsz + 1023) // 1024
+
+    def noise(salt):
+        return ((_hash2d(seed, salt, rows, 1024) >> np.uint64(29)) & np.uint64(0xFF)).astype(np.uint8).ravel()[:fsz]
+    if kind == "noise":
+        return np.stack([noise(f) for f in range(nframes)])
+    if kind == "extremes":
+        return np.stack([np.where(noise(f) & 1, 255, 0).astype(np.uint8) for f in range(nframes)])
+    if kind == "flat":
+        return np.full((nframes, fsz), (seed * 37 + 11) % 256, np.uint8)
+    if kind == "gradient":
+        base = np.arange(fsz, dtype=np.int64) * (1 + seed % 6) // 3
+        return np.stack([((base + 3 * f) % 256).astype(np.uint8) for f in range(nframes)])
+    if kind == "repeat":
+        return np.repeat(noise(0)[None, :], nframes, axis=0)
+    raise ValueError(kind)

@@ -38,6 +38,25 @@ def test_random_clip_sequences(name, n, q, period):
         assert np.array_equal(o[k], r[k]), (k, first)
 
 
+@pytest.mark.parametrize("rep", range(6))
+def test_random_geometry_and_quantisers(rep):
+    """Any multiple of 16 and any quantiser pair: the reference's frame functions (not its CLI, which hard-codes CIF) against the
+    restatement on fresh random shapes, contents and GOP lengths."""
+    rng = np.random.default_rng()
+    w, h = 16 * int(rng.integers(2, 30)), 16 * int(rng.integers(1, 20))
+    n = int(rng.integers(1, 6))
+    period = int(rng.choice([0, 1, 2, 3, 5]))
+    qdc, qac = (int(rng.choice([1, 2, 3, 5, 8, 16, 31, 64, 255])) for _ in range(2))
+    kind = str(rng.choice(["noise", "extremes", "flat", "gradient", "repeat", "clip"]))
+    seed = int(rng.integers(0, 1 << 20))
+    clip = (clipgen.synth_clip("footballlike", n, width=w, height=h, first_frame=seed % 50) if kind == "clip"
+            else clipgen.hashed_clip(kind, seed, n, w, h))
+    o = po.encode_sequence(clip, w, h, qdc, qac, period)
+    r = po.ref_encode_frames(clip, w, h, qdc, qac, period)
+    for k in ("levels", "acflag", "mpm", "mvd", "recon"):
+        assert np.array_equal(o[k], r[k]), (k, w, h, n, period, qdc, qac, kind, seed)
+
+
 def test_me_with_exact_copies_and_state_carry():
     rng = np.random.default_rng()
     prev = rng.integers(0, 256, (H, W)).astype(np.uint8)
