@@ -297,9 +297,28 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
 
 // ------------------------------------------------------------------------------------------------ host side
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e_); return ICSP_ERR_HIP; } } while (0)
+// The launch path (kernel launches, event records, cross-stream waits): a failure there can silently remove an ordering edge
+// and produce wrong bits, so it POISONS the context -- this call and every later one on the context return ICSP_ERR_HIP
+// (icsp_last_error names the first failed call) until the context is destroyed.
+#define HIPQ(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return poison(ctx, #call, e_); } while (0)
+// every entry point that works on a context's device state
+#define ENTER(ctx) do { if (!(ctx)) return ICSP_ERR_UNENOUGH_PARAM; if ((ctx)->sticky) return (ctx)->sticky; } while (0)
 
 struct EvPair { hipEvent_t a, b; int kernel; };
 constexpr int kMaxPGroups = 3;
+constexpr int kMaxFlights = 4;
+// A range of frame slots whose encode may still be running on the context's streams and has not been joined onto `stream`.
+// Two encodes need no ordering between them when their ranges are disjoint (closed GOPs / independent frames: the reference's
+// GOP jobs, ENC:186-213) or identical (the same partition onto the same streams: stream order does it); anything else
+// joins everything first.
+// How a range is laid onto the streams is decided when its record is made and kept while it is in flight:
+//   split (whole == false): the range's GOP groups / all-intra parts on `stream` and the group streams -- best when the same
+//     range is encoded again and again, since only its own parts can run beside each other;
+//   whole: everything on ONE of the two chain streams (sidx: 0 = `stream`, 1 = pstream[1]), ranges taking turns -- best when
+//     the caller alternates between independent ranges: two whole ranges are in flight side by side instead of two halves.
+//     Calls take the two streams in turn; a range that comes back on the other stream first waits for its own previous pass
+//     (ev_done, recorded behind every whole pass), so three or more ranges in rotation load both streams evenly.
+struct Flight { int first, n; bool used, whole, done_valid; int sidx; hipEvent_t ev_done; hipEvent_t ev_p1[kMaxPGroups]; };    // ev_p1[k]: group k's first P step of the last pass over this range is done
 
 } // namespace
 
@@ -315,10 +334,14 @@ struct icsp_ctx {
     // after other work was queued on `stream` (st_ahead) or when an outside producer uses the stream (always_sync)
     bool s2_dirty, st_ahead, always_sync;
     // IPPP batches: the I frames run on stream2, every GOP group's P steps are a chain on the group's own stream, and
-    // consecutive encodes of the SAME range overlap across calls as far as the data allow (encode_range).  p_dirty: the group
-    // streams carry work `stream` has not been ordered after yet; last_first / last_n: the range that work belongs to.
+    // consecutive encodes overlap across calls as far as the data allow (encode_range): encodes of disjoint ranges, or of
+    // the same range again, are not ordered against each other at all.  p_dirty: the group streams carry work `stream` has
+    // not been ordered after yet; flight[]: the ranges that un-joined work belongs to.
     bool p_dirty;
-    int last_first, last_n;
+    Flight flight[kMaxFlights];
+    int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
+    bool whole_ok;                    // ICSP_WHOLE=0: never place a range whole on one stream (comparison)
+    int sticky;                       // ICSP_ERR_HIP once a call of the launch path has failed (HIPQ): the context is poisoned
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
     int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
     int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
@@ -327,7 +350,6 @@ struct icsp_ctx {
                                       // milliseconds to create, and an all-intra encode never needs them)
     hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
     hipEvent_t ev_pjoin[kMaxPGroups];
-    hipEvent_t ev_p1[kMaxPGroups];    // group k's first P step of the last IPPP pass is done (recorded on the group's stream)
     DevBufs b;
     PackBufs pk;                      // device bit packer scratch + body buffer, allocated on first icsp_pack_bits
     size_t pk_cap;                    // bytes of pk.out
@@ -389,24 +411,36 @@ void build_me_tables(MeTables& t)
 
 int collect_profile(icsp_ctx* ctx);
 
+int poison(icsp_ctx* ctx, const char* what, hipError_t e)
+{
+    if (!ctx->sticky) ctx->err = std::string(what) + ": " + hipGetErrorString(e) + " (launch path: the context is unusable from here on)";
+    ctx->sticky = ICSP_ERR_HIP;
+    return ICSP_ERR_HIP;
+}
+
+// f() launches kernels on `st`; the launch status is checked here (hipLaunchKernelGGL itself returns nothing)
 template <typename F> int launch_timed(icsp_ctx* ctx, int kernel, hipStream_t st, F&& f)
 {
-    if (!ctx->profiling || !((ctx->prof_mask >> kernel) & 1u)) { f(); return 0; }
+    if (!ctx->profiling || !((ctx->prof_mask >> kernel) & 1u)) { f(); HIPQ(hipGetLastError()); return 0; }
     if (ctx->ev_pool.empty() && ctx->ev_pending.size() >= 8192) collect_profile(ctx);     // keeps the list bounded (this one blocks)
     EvPair e;
     if (!ctx->ev_pool.empty()) { e = ctx->ev_pool.back(); ctx->ev_pool.pop_back(); }
     else {
         // no event to be had: the launch itself must still happen, it just goes untimed
-        if (hipEventCreate(&e.a) != hipSuccess) { f(); return 0; }
-        if (hipEventCreate(&e.b) != hipSuccess) { hipEventDestroy(e.a); f(); return 0; }
+        if (hipEventCreate(&e.a) != hipSuccess) { (void)hipGetLastError(); f(); HIPQ(hipGetLastError()); return 0; }
+        if (hipEventCreate(&e.b) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e.a); f(); HIPQ(hipGetLastError()); return 0; }
     }
     e.kernel = kernel;
-    hipEventRecord(e.a, st);
+    const hipError_t ea = hipEventRecord(e.a, st);
     f();
-    hipEventRecord(e.b, st);
-    ctx->ev_pending.push_back(e);
+    const hipError_t el = hipGetLastError();
+    const hipError_t eb = hipEventRecord(e.b, st);
+    if (ea == hipSuccess && eb == hipSuccess) ctx->ev_pending.push_back(e);
+    else { (void)hipGetLastError(); ctx->ev_pool.push_back(e); }       // timing events order nothing: a failed record only loses the sample
+    HIPQ(el);
     return 0;
 }
+#define LT(...) do { if (int rc_ = launch_timed(__VA_ARGS__)) return rc_; } while (0)
 
 int collect_profile(icsp_ctx* ctx)
 {
@@ -414,7 +448,7 @@ int collect_profile(icsp_ctx* ctx)
         float ms = 0;
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
             ctx->prof_ms[e.kernel] += ms; ctx->prof_n[e.kernel] += 1;
-        }
+        } else (void)hipGetLastError();
         ctx->ev_pool.push_back(e);
     }
     ctx->ev_pending.clear();
@@ -443,19 +477,31 @@ int intra_waves_needed(const Geo& g)
 void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st);
 
 // Orders `stream` after everything queued on the context's other streams (chroma stream, GOP-group streams): called by whatever
-// reads results, uploads, or encodes a different range.
-void join_s2(icsp_ctx* ctx)
+// reads results, uploads, decodes, or encodes a range that partly overlaps one in flight.  No range is "in flight" afterwards.
+int join_all(icsp_ctx* ctx)
 {
     if (ctx->s2_dirty) {
-        hipEventRecord(ctx->ev_join, ctx->stream2);
-        hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0);
+        HIPQ(hipEventRecord(ctx->ev_join, ctx->stream2));
+        HIPQ(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
         ctx->s2_dirty = false;
     }
     if (ctx->p_dirty) {
         for (int k = 1; k < kMaxPGroups; k++)
-            if (ctx->pstream[k]) { hipEventRecord(ctx->ev_pjoin[k], ctx->pstream[k]); hipStreamWaitEvent(ctx->stream, ctx->ev_pjoin[k], 0); }
+            if (ctx->pstream[k]) { HIPQ(hipEventRecord(ctx->ev_pjoin[k], ctx->pstream[k])); HIPQ(hipStreamWaitEvent(ctx->stream, ctx->ev_pjoin[k], 0)); }
         ctx->p_dirty = false;
     }
+    for (auto& f : ctx->flight) f.used = false;
+    return 0;
+}
+
+// the chroma stream and every GOP-group stream that exists follow what has been queued on `stream` so far (uploads, a join)
+int fork_all(icsp_ctx* ctx)
+{
+    HIPQ(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPQ(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    for (int k = 1; k < kMaxPGroups; k++) if (ctx->pstream[k]) HIPQ(hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0));
+    ctx->st_ahead = false;
+    return 0;
 }
 
 // the streams of GOP groups 1.. are created by the first encode that needs them (a stream costs 2-10 ms), or by icsp_prepare
@@ -465,9 +511,45 @@ int group_streams(icsp_ctx* ctx, int ng)
         if (!ctx->pstream[k]) {
             HIPCHK(hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, ctx->prio_hi));
             HIPCHK(hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming));
+            ctx->st_ahead = true;                       // a new stream is ordered after nothing: the next encode forks
         }
+    return 0;
+}
+
+// Admission of an encode of slots [first, first + n): finds or makes the range's flight record.
+//   *same: the very same range is in flight (and allow_same): the new pass follows the old one stream by stream, no fork, no join;
+//   *joined: the range partly overlapped one in flight (or the table was full): everything was joined onto `stream`, the
+//            caller must fork.  A range disjoint from everything in flight needs neither.
+//   whole: the placement this call wants (see Flight); a record of the same range with the other placement is a conflict
+//          like a partial overlap (the range's frames would change streams), resolved the same way.
+int flight_admit(icsp_ctx* ctx, int first, int n, bool allow_same, bool whole, Flight** out, bool* same, bool* joined)
+{
+    *same = false; *joined = false;
+    Flight* hit = nullptr;
+    bool overlap = false;
+    for (auto& f : ctx->flight) {
+        if (!f.used) continue;
+        if (f.first == first && f.n == n) { hit = &f; continue; }
+        if (first < f.first + f.n && f.first < first + n) overlap = true;
+    }
+    if (hit && allow_same && !overlap && hit->whole == whole) { *same = true; *out = hit; return 0; }
+    Flight* slot = nullptr;
+    if (!hit && !overlap) for (auto& f : ctx->flight) if (!f.used) { slot = &f; break; }
+    if (!slot) {
+        if (int rc = join_all(ctx)) return rc;
+        *joined = true;
+        slot = &ctx->flight[0];
+    }
+    slot->used = true; slot->first = first; slot->n = n; slot->whole = whole; slot->sidx = 0; slot->done_valid = false;
+    *out = slot;
+    return 0;
+}
+
+int flight_events(icsp_ctx* ctx, Flight* f, int ng)
+{
     for (int k = 0; k < ng && k < kMaxPGroups; k++)
-        if (!ctx->ev_p1[k]) HIPCHK(hipEventCreateWithFlags(&ctx->ev_p1[k], hipEventDisableTiming));
+        if (!f->ev_p1[k]) HIPCHK(hipEventCreateWithFlags(&f->ev_p1[k], hipEventDisableTiming));
+    if (f->whole && !f->ev_done) HIPCHK(hipEventCreateWithFlags(&f->ev_done, hipEventDisableTiming));
     return 0;
 }
 
@@ -486,78 +568,90 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // per frame) and leaves most of the chip idle, so the GOPs are split into groups, each running its own chain on its own
     // stream: one group's serial kernel overlaps the others' search and residual kernels.  Groups touch disjoint frames,
     // hence disjoint slots of every buffer.
+    const bool lazy = !ctx->always_sync;
+    // A caller that alternates between independent ranges (this call's range is not the previous call's and does not touch
+    // it) gets every range WHOLE on one of the two chain streams, taking turns: two whole batches side by side keep twice the
+    // frames in flight that the two halves of one batch do.
+    const bool whole = lazy && ctx->whole_ok && ctx->last_n > 0 && (first >= ctx->last_first + ctx->last_n || ctx->last_first >= first + n);
+    ctx->last_first = first; ctx->last_n = n;
     int NG = ctx->p_groups;
     if (NG > G / 4) NG = G / 4;                        // keep every group's launches wide enough to be worth splitting
-    if (NG < 1 || L == 1) NG = 1;
+    if (NG < 1 || L == 1 || whole) NG = 1;
     auto group_lo = [&](int k) { return (int)((long long)G * k / NG); };
+    // Which ranges are in flight decides the ordering against earlier calls (flight_admit): the same range again, or a range
+    // disjoint from all of them -- the next chunk of a clip, the reference's independent GOP jobs (ENC:186-213) -- is not
+    // ordered against them at all; the chroma / group streams follow `stream` (fork) only when it carries something they must
+    // wait for (an upload, a join).
+    Flight* F = nullptr;
+    bool same = false, joined = false;
+    if (int rc = flight_admit(ctx, first, n, lazy, whole, &F, &same, &joined)) return rc;
+    if (int rc = flight_events(ctx, F, NG)) return rc;
+    bool moved = false;                                // a whole range on the other stream than its previous pass
+    if (whole) {
+        if (int rc = group_streams(ctx, 2)) return rc;
+        moved = same && F->sidx != ctx->rr;
+        F->sidx = ctx->rr; ctx->rr ^= 1;               // calls take the two chain streams in turn
+    }
+    // stream of chain / part k of this range
+    auto chain_stream = [&](int k) { return whole ? (F->sidx ? ctx->pstream[1] : st) : (k == 0 ? st : ctx->pstream[k]); };
+    if (moved && F->done_valid) HIPQ(hipStreamWaitEvent(chain_stream(0), F->ev_done, 0));
     if (L == 1) {
         // ---- all-intra: the I frame of every GOP.  Chroma of an I frame does not depend on its luma (no pixel prediction,
         //      ENC:4347-4349), so its kernels run on a second stream beside the latency-bound luma wavefront kernel.
         FrameSel fs{ first, L, G };
-        const bool lazy = !ctx->always_sync;
         // More frames than CUs: some CUs carry two frames and finish half again as late as the others, and a launch lasts as
         // long as its slowest workgroup.  Two launches on two streams (unequal parts, so that they do not fall into step), each
-        // following only its own previous pass, keep the early finishers busy: when the same range is encoded again, a part
-        // starts as soon as its own previous pass is through (300 CIF frames: 0.94 M -> 1.04 M frames/s; 600: +1 %).
-        const int NGI = G > ctx->n_cu ? ctx->i_groups : 1;
-        const bool same_i = NGI > 1 && ctx->p_dirty && lazy && ctx->last_first == first && ctx->last_n == n;
-        if (ctx->p_dirty && !same_i) { join_s2(ctx); ctx->st_ahead = true; }
+        // following only what its own stream carries, keep the early finishers busy: a part starts as soon as the part before
+        // it on its stream is through (300 CIF frames: 0.94 M -> 1.04 M frames/s; 600: +1 %).
+        const int NGI = (G > ctx->n_cu && !whole) ? ctx->i_groups : 1;
         if (NGI > 1) { if (int rc = group_streams(ctx, NGI)) return rc; }
-        if (!same_i && (NGI > 1 || !lazy || ctx->st_ahead)) {
-            hipEventRecord(ctx->ev_fork, st);
-            hipStreamWaitEvent(s2, ctx->ev_fork, 0);
-            for (int k = 1; k < NGI; k++) hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0);
-            ctx->st_ahead = false;
-        }
+        if (!same && (joined || !lazy || ctx->st_ahead)) { if (int rc = fork_all(ctx)) return rc; }
         for (int k = 0; k < NGI; k++) {
             const int g0 = k == 0 ? 0 : 2 * G / 5, g1 = k + 1 == NGI ? G : 2 * G / 5;
-            hipStream_t sk = k == 0 ? st : ctx->pstream[k];
+            hipStream_t sk = chain_stream(k);
             FrameSel fk{ first + g0, L, g1 - g0 };
-            launch_timed(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, G, sk); });
+            // frames in flight at once (which decides the kernel form): whole placement -> another batch like this one beside it
+            LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? 2 * G : G, sk); });
         }
-        launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
+        LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
-        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
+        LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         ctx->s2_dirty = true;
-        if (NGI > 1) { ctx->p_dirty = true; ctx->last_first = first; ctx->last_n = n; }
-        if (!lazy) join_s2(ctx);
-        HIPCHK(hipGetLastError());
+        if (NGI > 1 || (whole && F->sidx)) ctx->p_dirty = true;
+        if (whole) { HIPQ(hipEventRecord(F->ev_done, chain_stream(0))); F->done_valid = true; }
+        if (!lazy) { if (int rc = join_all(ctx)) return rc; }
         return 0;
     }
     // ---- IPPP.  The I frames of all groups run on stream2 (chroma kernels, then the luma wavefront kernel); every group's P
-    // steps are one chain on the group's own stream, which waits for the I frames.  When this call encodes the same range as
-    // the one before and nothing else has touched the context since, the passes overlap as far as the data allow: a group's
-    // chain follows its own previous pass in stream order, and the I frames only wait for the FIRST P step of every group's
-    // previous pass -- the last reader of what the I kernels overwrite (the I frames' reconstruction; later P steps read and
-    // write their own slots and the slot before them only).  So the I frames of pass N+1, a latency-bound launch on a few
-    // CUs, run beside P steps 2.. of pass N instead of in front of an idle chip.  Anything else first joins everything onto
-    // `stream` (join_s2).
-    const bool same = ctx->p_dirty && !ctx->always_sync && ctx->last_first == first && ctx->last_n == n;
-    if (!same) join_s2(ctx);
+    // steps are one chain on the group's own stream, which waits for the I frames.  When the same range is encoded again while
+    // in flight, the passes overlap as far as the data allow: a group's chain follows its own previous pass in stream order,
+    // and the I frames only wait for the FIRST P step of every group's previous pass over that range -- the last reader of what
+    // the I kernels overwrite (the I frames' reconstruction; later P steps read and write their own slots and the slot before
+    // them only).  So the I frames of the next pass, a latency-bound launch on a few CUs, run beside P steps 2.. of this one
+    // -- or beside another range's P steps -- instead of in front of an idle chip.
     if (int rc = group_streams(ctx, NG)) return rc;
-    if (same) { for (int k = 0; k < NG; k++) hipStreamWaitEvent(s2, ctx->ev_p1[k], 0); }
-    else { hipEventRecord(ctx->ev_fork, st); hipStreamWaitEvent(s2, ctx->ev_fork, 0); }   // after what was queued on `stream` (uploads ...)
+    if (same) { for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(s2, F->ev_p1[k], 0)); }
+    else if (joined || !lazy || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }   // after what was queued on `stream` (uploads ...)
     {
         FrameSel fs{ first, L, G };
-        launch_timed(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
+        LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
-        launch_timed(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
-        launch_timed(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2); });
-        hipEventRecord(ctx->ev_join, s2);
-        for (int k = 0; k < NG; k++) hipStreamWaitEvent(k == 0 ? st : ctx->pstream[k], ctx->ev_join, 0);
+        LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
+        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2); });
+        HIPQ(hipEventRecord(ctx->ev_join, s2));
+        for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(chain_stream(k), ctx->ev_join, 0));
     }
-    ctx->s2_dirty = false;                             // every chain, `stream` among them, is ordered after stream2's work
-    ctx->st_ahead = true;
-    ctx->p_dirty = true;
-    ctx->last_first = first; ctx->last_n = n;
+    // every chain is ordered after stream2's work; `stream` itself is one of them unless the range went whole onto the group stream
+    if (whole && F->sidx) ctx->s2_dirty = true; else ctx->s2_dirty = false;
+    if (NG > 1 || (whole && F->sidx)) ctx->p_dirty = true;
     for (int i = 1; i < L; i++) {
         bool any = false;
         for (int k = 0; k < NG; k++) {
             const int g0 = group_lo(k), g1 = group_lo(k + 1);
             int Gi = 0;
             for (int gop = g0; gop < g1; gop++) if (gop * L + i < n) Gi++;
-            hipStream_t sk = k == 0 ? st : ctx->pstream[k];
-            if (Gi == 0) { if (i == 1) hipEventRecord(ctx->ev_p1[k], sk); continue; }
+            hipStream_t sk = chain_stream(k);
+            if (Gi == 0) { if (i == 1) HIPQ(hipEventRecord(F->ev_p1[k], sk)); continue; }
             any = true;
             FrameSel fs{ first + g0 * L + i, L, Gi };
             const size_t serial_lds = serial_lds_bytes(g.nmb, g.sw, g.sh);
@@ -574,20 +668,23 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             int run = (int)(((long long)Gi * tiles + 4095) / 4096);
             run = run < 1 ? 1 : (run > 32 ? 32 : run);
             const int runs = (tiles + run - 1) / run, sf_ = xcd_slices(Gi, runs);
-            launch_timed(ctx, ICSP_K_ME, sk, [&] {
+            LT(ctx, ICSP_K_ME, sk, [&] {
                 hipLaunchKernelGGL((k_me<false>), xcd_grid2(Gi, tiles, st_), dim3(256), 0, sk, g, fs, b, tiles, st_, 1);
                 if (!fused) hipLaunchKernelGGL((k_me<true>), xcd_grid2(Gi, runs, sf_), dim3(256), 0, sk, g, fs, b, tiles, sf_, run);
             });
-            launch_timed(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
+            LT(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
                 if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, runs, sf_)), dim3(256), serial_lds, sk, g, fs, b, (int)n_serial8, runs, sf_, run, tiles);
                 else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
             });
-            launch_timed(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(Gi, res_wgs, sr_), dim3(256), 0, sk, g, fs, b, 1, res_wgs, sr_); });
-            if (i == 1) hipEventRecord(ctx->ev_p1[k], sk);             // the I frames of the next pass may start
+            LT(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(Gi, res_wgs, sr_), dim3(256), 0, sk, g, fs, b, 1, res_wgs, sr_); });
+            if (i == 1) HIPQ(hipEventRecord(F->ev_p1[k], sk));             // the I frames of the next pass over this range may start
         }
         if (!any) break;
     }
-    HIPCHK(hipGetLastError());
+    if (L > 1 && n <= 1) { for (int k = 0; k < NG; k++) HIPQ(hipEventRecord(F->ev_p1[k], chain_stream(k))); }   // (no P step at all)
+    if (whole) { HIPQ(hipEventRecord(F->ev_done, chain_stream(0))); F->done_valid = true; }
+    // a zero-copy consumer on `stream` (icsp_device_view) must find every group's results ordered before it
+    if (!lazy) { if (int rc = join_all(ctx)) return rc; }
     return 0;
 }
 
@@ -608,16 +705,16 @@ int decode_range(icsp_ctx* ctx, int first, int n)
     b.coef = nullptr;
     hipStream_t st = ctx->stream, s2 = ctx->stream2;
     const int G = (n + L - 1) / L;
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     ctx->st_ahead = true;
-    launch_timed(ctx, ICSP_K_DECODE, st, [&] {
+    LT(ctx, ICSP_K_DECODE, st, [&] {
         hipLaunchKernelGGL(k_dec_serial, dim3(n), dim3(256), (size_t)g.nmb * 16, st, g, first, n, L, b);
     });
     {
         FrameSel fs{ first, L, G };
-        hipEventRecord(ctx->ev_fork, st);
-        hipStreamWaitEvent(s2, ctx->ev_fork, 0);
-        launch_timed(ctx, ICSP_K_DECODE, st, [&] {
+        HIPQ(hipEventRecord(ctx->ev_fork, st));
+        HIPQ(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+        LT(ctx, ICSP_K_DECODE, st, [&] {
             const int diag = g.rows8 < g.cols8 ? g.rows8 : g.cols8;              // widest anti-diagonal, 2 blocks per wave
             const int need = (diag + 1) / 2;
             const int nw = (G > ctx->n_cu) ? (need < 8 ? need : 8) : need;
@@ -629,9 +726,9 @@ int decode_range(icsp_ctx* ctx, int first, int n)
             else               launch_dec_luma<16>(g, fs, b, G, st);
         });
         const long long nblk = (long long)G * g.nmb * 2;
-        launch_timed(ctx, ICSP_K_DECODE, s2, [&] { hipLaunchKernelGGL(k_dec_blocks, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s2, g, fs, b, 4, 2, 0); });
-        hipEventRecord(ctx->ev_join, s2);
-        hipStreamWaitEvent(st, ctx->ev_join, 0);
+        LT(ctx, ICSP_K_DECODE, s2, [&] { hipLaunchKernelGGL(k_dec_blocks, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s2, g, fs, b, 4, 2, 0); });
+        HIPQ(hipEventRecord(ctx->ev_join, s2));
+        HIPQ(hipStreamWaitEvent(st, ctx->ev_join, 0));
     }
     for (int i = 1; i < L; i++) {
         int Gi = 0;
@@ -639,9 +736,8 @@ int decode_range(icsp_ctx* ctx, int first, int n)
         if (Gi == 0) break;
         FrameSel fs{ first + i, L, Gi };
         const long long nblk = (long long)Gi * g.nmb * 6;
-        launch_timed(ctx, ICSP_K_DECODE, st, [&] { hipLaunchKernelGGL(k_dec_blocks, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
+        LT(ctx, ICSP_K_DECODE, st, [&] { hipLaunchKernelGGL(k_dec_blocks, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
     }
-    HIPCHK(hipGetLastError());
     return 0;
 }
 
@@ -728,9 +824,9 @@ void icsp_host_free(void* p) { if (p) (void)hipHostFree(p); }
 // (tools/probe_duplex.hip: 17.0 -> 11.1 ms for 456 MB each way).
 int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     HIPCHK(hipSetDevice(ctx->device));
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     if (!shared) { ctx->up_stream = ctx->down_stream = nullptr; return ICSP_OK; }
     static std::mutex m;
@@ -745,12 +841,17 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
         // icsp_enc process in thirty still ends up with all its transfers taking turns, 18 ms instead of 13.6 for 3000 frames;
         // one in thirteen before uploads and downloads were made one at a time per stream.)
         hipStream_t a = nullptr, b = nullptr;
-        HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
         uint8_t* h = nullptr;
         const size_t nb = (size_t)8 << 20;
         uint8_t* dv = nullptr;                                         // device scratch: nothing of the context is touched
+        // whatever leaves this block early (a failed stream creation) must not leak the probe's stream and its two 16 MB buffers
+        struct Probe { hipStream_t* a; hipStream_t* b; uint8_t** h; uint8_t** dv; bool keep;
+                       ~Probe() { if (*h) (void)hipHostFree(*h); if (*dv) (void)hipFree(*dv);
+                                  if (!keep) { if (*a) (void)hipStreamDestroy(*a); if (*b) (void)hipStreamDestroy(*b); }
+                                  (void)hipGetLastError(); } } probe{ &a, &b, &h, &dv, false };
+        HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
         if (hipHostMalloc((void**)&h, 2 * nb, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h = nullptr; }
-        if (h && hipMalloc((void**)&dv, 2 * nb) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); h = nullptr; }
+        if (h && hipMalloc((void**)&dv, 2 * nb) != hipSuccess) { (void)hipGetLastError(); dv = nullptr; (void)hipHostFree(h); h = nullptr; }
         if (dv) (void)hipMemset(dv, 0, 2 * nb);
         auto seconds = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         if (h) {
@@ -780,9 +881,7 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
             if (t_both < 0.8 * t_seq) break;
             if (attempt < 3) { (void)hipStreamDestroy(b); b = nullptr; }
         }
-        if (h) (void)hipHostFree(h);
-        if (dv) (void)hipFree(dv);
-        (void)hipGetLastError();
+        probe.keep = true;                                             // (the buffers go with the guard)
         up[d] = a; down[d] = b;
     }
     ctx->up_stream = up[d]; ctx->down_stream = down[d];
@@ -846,10 +945,13 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
     ctx->up_stream = nullptr; ctx->down_stream = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
-    ctx->p_dirty = false; ctx->last_first = -1; ctx->last_n = -1;
+    ctx->p_dirty = false; ctx->sticky = 0;
+    memset(ctx->flight, 0, sizeof(ctx->flight));
+    ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0;
+    { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
     ctx->force_intra_nw = 0; ctx->force_intra_form = 0;
-    for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; ctx->ev_p1[k] = nullptr; }
+    for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured (300 CIF frames, period 10): 1 group 0.75 M frames/s, 2 groups 0.89 M, 3 groups -- a fourth
                                        // busy stream of the context -- 0.27 M, whatever the stream priorities and GPU_MAX_HW_QUEUES
     ctx->i_groups = 2;
@@ -863,7 +965,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     hipError_t e;
     // the main stream carries the latency-bound kernels and gets the higher priority; stream2 (I-frame chroma) fills in
     int prio_lo = 0, prio_hi = 0;
-    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { (void)hipGetLastError(); prio_lo = prio_hi = 0; }
     if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
     if ((e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
@@ -887,15 +989,17 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ALLOC(ctx->b.me_ent, nf * nmb * 4 * sizeof(uint32_t));
     ALLOC(ctx->b.me_sums, nf * nmb * 24 * sizeof(int16_t));
     ALLOC(ctx->b.me_flag, nf * sizeof(int));
-    hipMemsetAsync(ctx->b.me_flag, 0, nf * sizeof(int), ctx->stream);
     ALLOC(ctx->b.me_done, nf * sizeof(int));
-    hipMemsetAsync(ctx->b.me_done, 0, nf * sizeof(int), ctx->stream);
     ALLOC(ctx->b.dcpred, nf * nmb * 6 * sizeof(int16_t));
 #undef ALLOC
-    hipMemsetAsync(ctx->b.mpm, 0, nf * nmb * 4, ctx->stream);
-    hipMemsetAsync(ctx->b.mvd, 0, nf * nmb * 2, ctx->stream);
-    hipMemsetAsync(ctx->b.mv, 0, nf * nmb * 2, ctx->stream);
-    hipMemsetAsync(ctx->b.imode, 0, nf * nmb * 4, ctx->stream);
+#define ZERO(ptr, bytes) if ((e = hipMemsetAsync((ptr), 0, (bytes), ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipMemsetAsync " #ptr, e)
+    ZERO(ctx->b.me_flag, nf * sizeof(int));            // k_me raises it, the serial kernel of the same step clears it
+    ZERO(ctx->b.me_done, nf * sizeof(int));            // arrival tickets: 0 between launches
+    ZERO(ctx->b.mpm, nf * nmb * 4);
+    ZERO(ctx->b.mvd, nf * nmb * 2);
+    ZERO(ctx->b.mv, nf * nmb * 2);
+    ZERO(ctx->b.imode, nf * nmb * 4);
+#undef ZERO
     {   // the search tables are the same for every context: once per device and process (the call costs 7-12 ms)
         static std::mutex m;
         static bool loaded[64] = {};
@@ -914,23 +1018,25 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
 int icsp_destroy(icsp_ctx_t* ctx)
 {
     if (!ctx) return ICSP_OK;
-    hipSetDevice(ctx->device);
-    if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    if (ctx->stream2) hipStreamSynchronize(ctx->stream2);
-    for (int k = 1; k < kMaxPGroups; k++) if (ctx->pstream[k]) hipStreamSynchronize(ctx->pstream[k]);
-    for (auto& e : ctx->ev_pending) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-    for (auto& e : ctx->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-    hipFree(ctx->d_frames); hipFree(ctx->b.recon); hipFree(ctx->b.levels); hipFree(ctx->b.acflag); hipFree(ctx->b.mpm);
-    hipFree(ctx->b.mvd); hipFree(ctx->b.mv); hipFree(ctx->b.imode); hipFree(ctx->b.me_ent); hipFree(ctx->b.me_sums); hipFree(ctx->b.me_flag); hipFree(ctx->b.me_done);
-    hipFree(ctx->b.dcpred); hipFree(ctx->b.coef);
-    hipFree(ctx->pk.grp_bits); hipFree(ctx->pk.grp_off); hipFree(ctx->pk.chunk_bits); hipFree(ctx->pk.chunk_base); hipFree(ctx->pk.out);
-    if (ctx->pk_host) hipHostFree(ctx->pk_host);
-    if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
-    for (int k = 0; k < kMaxPGroups; k++) if (ctx->ev_p1[k]) hipEventDestroy(ctx->ev_p1[k]);
-    if (ctx->stream2) hipStreamDestroy(ctx->stream2);
-    for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) hipEventDestroy(ctx->ev_pjoin[k]); if (ctx->pstream[k]) hipStreamDestroy(ctx->pstream[k]); }
-    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    // best effort from here on: nothing can be done about a failing call, and none of them orders anything
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
+    for (int k = 1; k < kMaxPGroups; k++) if (ctx->pstream[k]) (void)hipStreamSynchronize(ctx->pstream[k]);
+    for (auto& e : ctx->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    void* bufs[] = { ctx->d_frames, ctx->b.recon, ctx->b.levels, ctx->b.acflag, ctx->b.mpm, ctx->b.mvd, ctx->b.mv, ctx->b.imode, ctx->b.me_ent,
+                     ctx->b.me_sums, ctx->b.me_flag, ctx->b.me_done, ctx->b.dcpred, ctx->b.coef, ctx->pk.grp_bits, ctx->pk.grp_off,
+                     ctx->pk.chunk_bits, ctx->pk.chunk_base, ctx->pk.out };
+    for (void* q : bufs) if (q) (void)hipFree(q);
+    if (ctx->pk_host) (void)hipHostFree(ctx->pk_host);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    for (auto& f : ctx->flight) { if (f.ev_done) (void)hipEventDestroy(f.ev_done); for (int k = 0; k < kMaxPGroups; k++) if (f.ev_p1[k]) (void)hipEventDestroy(f.ev_p1[k]); }
+    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+    for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) (void)hipEventDestroy(ctx->ev_pjoin[k]); if (ctx->pstream[k]) (void)hipStreamDestroy(ctx->pstream[k]); }
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    (void)hipGetLastError();
     delete ctx;
     return ICSP_OK;
 }
@@ -973,10 +1079,11 @@ int copy_down_end(icsp_ctx* ctx)
 
 int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
 {
-    if (!ctx || !yuv) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
+    if (!yuv) return ICSP_ERR_UNENOUGH_PARAM;
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
-    join_s2(ctx);                                      // chroma kernels of an earlier encode may still read the frames
+    if (int rc = join_all(ctx)) return rc;                                      // chroma kernels of an earlier encode may still read the frames
     ctx->st_ahead = true;
     if (int rc = copy_up(ctx, ctx->d_frames + (size_t)first * ctx->g.fsz, yuv, (size_t)n * ctx->g.fsz)) return rc;
     return ICSP_OK;
@@ -987,7 +1094,8 @@ int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
 // context's own thread packs and downloads an earlier batch -- see icsp_hip.h for what the caller has to guarantee.
 int icsp_upload_sync(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
 {
-    if (!ctx || !yuv) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
+    if (!yuv) return ICSP_ERR_UNENOUGH_PARAM;
     if (int rc = check_range(ctx, first, n)) return rc;
     if (!ctx->up_stream) return ICSP_ERR_UNCORRECT_PARAM;
     if (hipSetDevice(ctx->device) != hipSuccess) return ICSP_ERR_HIP;
@@ -999,7 +1107,7 @@ int icsp_upload_sync(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
 
 int icsp_encode_resident(icsp_ctx_t* ctx, int first, int n)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     return encode_range(ctx, first, n);
@@ -1007,9 +1115,9 @@ int icsp_encode_resident(icsp_ctx_t* ctx, int first, int n)
 
 int icsp_sync(icsp_ctx_t* ctx)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     HIPCHK(hipSetDevice(ctx->device));
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     // event pairs are read out in icsp_profile_get / icsp_profile_reset, not here: a caller timing "launch ... icsp_sync"
     // must not pay for the bookkeeping of the profiler
@@ -1018,11 +1126,11 @@ int icsp_sync(icsp_ctx_t* ctx)
 
 int icsp_download(icsp_ctx_t* ctx, int first, int n, int16_t* levels, uint8_t* acflag, uint8_t* mpm, int8_t* mvd, uint8_t* recon)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nmb = ctx->g.nmb, f = first, c = n;
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     DownTurn turn;
     if (int rc = copy_down_begin(ctx, turn)) return rc;
     hipStream_t st = down_of(ctx);
@@ -1038,12 +1146,13 @@ int icsp_download(icsp_ctx_t* ctx, int first, int n, int16_t* levels, uint8_t* a
 
 int icsp_upload_syntax(icsp_ctx_t* ctx, int first, int n, const int16_t* levels, const uint8_t* mpm, const int8_t* mvd)
 {
-    if (!ctx || !levels || !mpm || !mvd) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
+    if (!levels || !mpm || !mvd) return ICSP_ERR_UNENOUGH_PARAM;
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nmb = ctx->g.nmb, f = first, c = n;
     hipStream_t st = ctx->stream;
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     ctx->st_ahead = true;
     HIPCHK(hipMemcpyAsync(ctx->b.levels + f * nmb * 384, levels, c * nmb * 384 * sizeof(int16_t), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->b.mpm + f * nmb * 4, mpm, c * nmb * 4, hipMemcpyHostToDevice, st));
@@ -1054,7 +1163,7 @@ int icsp_upload_syntax(icsp_ctx_t* ctx, int first, int n, const int16_t* levels,
 
 int icsp_decode_resident(icsp_ctx_t* ctx, int first, int n)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     return decode_range(ctx, first, n);
@@ -1089,8 +1198,10 @@ static int pack_alloc(icsp_ctx* ctx)
     if (e == hipSuccess) e = hipMalloc((void**)&ctx->pk.out, ctx->pk_cap);
     if (e == hipSuccess) e = hipHostMalloc((void**)&ctx->pk_host, 256, hipHostMallocDefault);     // total bits | head | tail
     if (e != hipSuccess) {
-        hipFree(ctx->pk.grp_bits); hipFree(ctx->pk.grp_off); hipFree(ctx->pk.chunk_bits); hipFree(ctx->pk.chunk_base); hipFree(ctx->pk.out);
-        if (ctx->pk_host) hipHostFree(ctx->pk_host);
+        (void)hipGetLastError();
+        void* bufs[] = { ctx->pk.grp_bits, ctx->pk.grp_off, ctx->pk.chunk_bits, ctx->pk.chunk_base, ctx->pk.out };
+        for (void* q : bufs) if (q) (void)hipFree(q);
+        if (ctx->pk_host) (void)hipHostFree(ctx->pk_host);
         memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_host = nullptr;
         ctx->err = std::string("hipMalloc bit packer: ") + hipGetErrorString(e);
         return ICSP_ERR_MEM_ALLOC;
@@ -1105,7 +1216,7 @@ static int pack_reserve(icsp_ctx* ctx, unsigned long long bits)
     const size_t need = pack_bytes(bits);
     if (need <= ctx->pk_cap) return ICSP_OK;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    hipFree(ctx->pk.out); ctx->pk.out = nullptr; ctx->pk_cap = 0;
+    (void)hipFree(ctx->pk.out); ctx->pk.out = nullptr; ctx->pk_cap = 0;
     const size_t want = need + need / 4;                               // headroom: the next batches are about as long
     if (hipMalloc((void**)&ctx->pk.out, want) != hipSuccess) {
         (void)hipGetLastError();
@@ -1124,13 +1235,14 @@ static int pack_check(icsp_ctx* ctx, int first, int n)
 
 int icsp_pack_count(icsp_ctx_t* ctx, int first, int n, uint64_t* nbits)
 {
-    if (!ctx || !nbits) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
+    if (!nbits) return ICSP_ERR_UNENOUGH_PARAM;
     if (int rc = pack_check(ctx, first, n)) return rc;
     *nbits = 0;
     ctx->pk_first = -1;
     if (n == 0) { ctx->pk_first = first; ctx->pk_n = 0; ctx->pk_total = 0; return ICSP_OK; }
     HIPCHK(hipSetDevice(ctx->device));
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     if (int rc = pack_alloc(ctx)) return rc;
     const Geo& g = ctx->g;
     const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
@@ -1139,12 +1251,11 @@ int icsp_pack_count(icsp_ctx_t* ctx, int first, int n, uint64_t* nbits)
     const int nchunk = (int)((ngrp + kChunkGrps - 1) / kChunkGrps);
     const DevBufs& b = ctx->b;
     const PackBufs& pk = ctx->pk;
-    launch_timed(ctx, ICSP_K_PACK, st, [&] {
+    LT(ctx, ICSP_K_PACK, st, [&] {
         hipLaunchKernelGGL(k_bits_count, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, g, first, n, L, ngrp, b, pk);
         hipLaunchKernelGGL(k_bits_scan, dim3(nchunk), dim3(256), 0, st, ngrp, pk);
         hipLaunchKernelGGL(k_chunk_base, dim3(1), dim3(256), 0, st, nchunk, pk);
     });
-    HIPCHK(hipGetLastError());
     unsigned long long* total = (unsigned long long*)ctx->pk_host;
     HIPCHK(hipMemcpyAsync(total, pk.chunk_base + nchunk, 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1163,17 +1274,17 @@ static int pack_write(icsp_ctx* ctx, int first, int n, unsigned sh)
     const long long ngrp = ((long long)n * g.nmb * 6 + kGrpUnits - 1) / kGrpUnits;
     const DevBufs& b = ctx->b;
     const PackBufs& pk = ctx->pk;
-    launch_timed(ctx, ICSP_K_PACK, st, [&] {
+    LT(ctx, ICSP_K_PACK, st, [&] {
         hipLaunchKernelGGL(k_pack_zero, dim3((unsigned)((ngrp + 255) / 256)), dim3(256), 0, st, ngrp, pk, sh);
         hipLaunchKernelGGL(k_pack, dim3((unsigned)((ngrp + 3) / 4)), dim3(256), 0, st, g, first, n, L, ngrp, b, pk, sh);
     });
-    HIPCHK(hipGetLastError());
     return ICSP_OK;
 }
 
 int icsp_pack_into(icsp_ctx_t* ctx, int first, int n, uint64_t at_bit, uint8_t* body_image, size_t cap)
 {
-    if (!ctx || !body_image) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
+    if (!body_image) return ICSP_ERR_UNENOUGH_PARAM;
     if (int rc = pack_check(ctx, first, n)) return rc;
     if (ctx->pk_first != first || ctx->pk_n != n) { ctx->err = "icsp_pack_into without icsp_pack_count of the same range"; return ICSP_ERR_RANGE; }
     if (ctx->pk_total == 0) return ICSP_OK;
@@ -1217,7 +1328,8 @@ int icsp_pack_into(icsp_ctx_t* ctx, int first, int n, uint64_t at_bit, uint8_t* 
 
 int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap, uint64_t* nbits)
 {
-    if (!ctx || !body || !nbits) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
+    if (!body || !nbits) return ICSP_ERR_UNENOUGH_PARAM;
     if (int rc = icsp_pack_count(ctx, first, n, nbits)) return rc;
     const uint64_t total = *nbits;
     if (total == 0) return ICSP_OK;
@@ -1236,9 +1348,10 @@ int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap,
 // the packer's scratch buffer to `pinned`, so a host can spend that during set-up on a range that must start out zeroed anyway.
 int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes)
 {
-    if (!ctx || !pinned) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
+    if (!pinned) return ICSP_ERR_UNENOUGH_PARAM;
     HIPCHK(hipSetDevice(ctx->device));
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     if (int rc = pack_alloc(ctx)) return rc;
     const size_t nb = std::min(bytes, (size_t)16 << 20), piece = std::min(nb, ctx->pk_cap);
     if (nb == 0) return ICSP_OK;
@@ -1255,11 +1368,11 @@ int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes)
 // batches calls this while it sets up (icsp_enc).  The frame store's first GOP is overwritten.
 int icsp_prepare(icsp_ctx_t* ctx)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
     const int n = std::min(ctx->max_frames, std::max(L, 2 * L <= ctx->max_frames ? 2 * L : L));    // two GOPs when they fit: both group streams
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     // batches of 8+ GOPs run as p_groups chains, all-intra batches of more frames than CUs in i_groups parts
     const int ngs = L > 1 ? (ctx->max_frames >= 8 * L ? ctx->p_groups : 1) : (ctx->max_frames > ctx->n_cu ? ctx->i_groups : 1);
     if (ngs > 1) {
@@ -1302,24 +1415,39 @@ int icsp_encode_gop(icsp_ctx_t* ctx, const uint8_t* yuv, int n, int16_t* levels,
     return icsp_download(ctx, 0, n, levels, acflag, mpm, mvd, recon);
 }
 
+// Scheduling knobs of one context (what ICSP_P_GROUPS / ICSP_I_GROUPS set for every context of the process): 0 keeps a value.
+// Results never depend on them.  Joins first, so the next encode starts from a clean slate whatever was in flight.
+int icsp_set_groups(icsp_ctx_t* ctx, int p_groups, int i_groups)
+{
+    ENTER(ctx);
+    if (p_groups < 0 || p_groups > kMaxPGroups || i_groups < 0 || i_groups > 2) return ICSP_ERR_UNCORRECT_PARAM;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int rc = join_all(ctx)) return rc;
+    ctx->st_ahead = true;
+    if (p_groups) ctx->p_groups = p_groups;
+    if (i_groups) ctx->i_groups = i_groups;
+    return ICSP_OK;
+}
+
 int icsp_device_view(icsp_ctx_t* ctx, icsp_device_view_t* v)
 {
-    if (!ctx || !v) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
+    if (!v) return ICSP_ERR_UNENOUGH_PARAM;
     v->frames = ctx->d_frames; v->levels = ctx->b.levels; v->acflag = ctx->b.acflag; v->mpm_mode = ctx->b.mpm;
     v->mvd = ctx->b.mvd; v->recon = ctx->b.recon; v->stream = (void*)ctx->stream;
     v->max_frames = ctx->max_frames; v->n_mb = ctx->g.nmb;
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     ctx->always_sync = true;           // an outside producer/consumer now shares `stream`: order stream2 against it every time
     return ICSP_OK;
 }
 
 int icsp_download_debug(icsp_ctx_t* ctx, int first, int n, int8_t* mv, uint8_t* imode)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nmb = ctx->g.nmb, f = first, c = n;
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     if (mv) HIPCHK(hipMemcpyAsync(mv, ctx->b.mv + f * nmb * 2, c * nmb * 2, hipMemcpyDeviceToHost, ctx->stream));
     if (imode) HIPCHK(hipMemcpyAsync(imode, ctx->b.imode + f * nmb * 4, c * nmb * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1328,7 +1456,7 @@ int icsp_download_debug(icsp_ctx_t* ctx, int first, int n, int8_t* mv, uint8_t* 
 
 int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     if (on && !ctx->b.coef) {
         hipError_t e = hipMalloc((void**)&ctx->b.coef, (size_t)ctx->max_frames * ctx->g.nmb * 384 * sizeof(double));
@@ -1340,12 +1468,13 @@ int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on)
 
 int icsp_download_coef(icsp_ctx_t* ctx, int first, int n, double* coef)
 {
-    if (!ctx || !coef) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
+    if (!coef) return ICSP_ERR_UNENOUGH_PARAM;
     if (!ctx->b.coef) return ICSP_ERR_UNCORRECT_PARAM;
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     const size_t per = (size_t)ctx->g.nmb * 384;
-    join_s2(ctx);
+    if (int rc = join_all(ctx)) return rc;
     HIPCHK(hipMemcpyAsync(coef, ctx->b.coef + (size_t)first * per, (size_t)n * per * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ICSP_OK;
@@ -1353,7 +1482,7 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first, int n, double* coef)
 
 int icsp_profile_enable(icsp_ctx_t* ctx, int on)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     ctx->profiling = on != 0;
     ctx->prof_mask = (on == 1) ? 0xffffffffu : ((unsigned)on >> 1);     // 1 = every kernel; otherwise bit (k+1) selects kernel k
     if (on) {
@@ -1362,7 +1491,7 @@ int icsp_profile_enable(icsp_ctx_t* ctx, int on)
         while (ctx->ev_pool.size() + ctx->ev_pending.size() < 256) {
             EvPair e;
             if (hipEventCreate(&e.a) != hipSuccess) break;
-            if (hipEventCreate(&e.b) != hipSuccess) { hipEventDestroy(e.a); break; }
+            if (hipEventCreate(&e.b) != hipSuccess) { (void)hipEventDestroy(e.a); break; }
             e.kernel = 0;
             ctx->ev_pool.push_back(e);
         }
@@ -1372,7 +1501,7 @@ int icsp_profile_enable(icsp_ctx_t* ctx, int on)
 
 int icsp_profile_reset(icsp_ctx_t* ctx)
 {
-    if (!ctx) return ICSP_ERR_UNENOUGH_PARAM;
+    ENTER(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     collect_profile(ctx);
@@ -1383,11 +1512,34 @@ int icsp_profile_reset(icsp_ctx_t* ctx)
 int icsp_profile_get(icsp_ctx_t* ctx, int kernel, double* total_ms, long long* launches)
 {
     if (!ctx || kernel < 0 || kernel >= ICSP_K_COUNT) return ICSP_ERR_UNCORRECT_PARAM;
+    if (ctx->sticky) return ctx->sticky;
     HIPCHK(hipSetDevice(ctx->device));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     collect_profile(ctx);
     if (total_ms) *total_ms = ctx->prof_ms[kernel];
     if (launches) *launches = ctx->prof_n[kernel];
+    return ICSP_OK;
+}
+
+// Test hook (tests/test_host_cpu.py, no device needed): a context shell in the state a failed launch-path call leaves behind.
+// Every entry point must keep answering ICSP_ERR_HIP without touching the runtime; icsp_destroy releases it.
+int icsp_debug_poisoned_context(icsp_ctx_t** out)
+{
+    if (!out) return ICSP_ERR_UNENOUGH_PARAM;
+    icsp_ctx* ctx = new (std::nothrow) icsp_ctx();
+    if (!ctx) return ICSP_ERR_MEM_ALLOC;
+    ctx->p = icsp_params_t{ 352, 288, 16, 16, 0 };
+    ctx->device = 0; ctx->max_frames = 1;
+    memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
+    memset(ctx->flight, 0, sizeof(ctx->flight));
+    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true;
+    ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
+    for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
+    ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
+    ctx->s2_dirty = ctx->st_ahead = ctx->always_sync = ctx->p_dirty = false;
+    ctx->keep_coef = ctx->profiling = false; ctx->prof_mask = 0;
+    poison(ctx, "icsp_debug_poisoned_context", hipErrorUnknown);
+    *out = ctx;
     return ICSP_OK;
 }
 

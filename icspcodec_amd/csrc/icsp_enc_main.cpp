@@ -310,11 +310,11 @@ int main(int argc, char* argv[])
     }
     nworker = std::max(1, std::min({ nworker, ngop, 64 }));
     // Several workers on a device already keep it busy from several streams; a second GOP-group stream in each context only
-    // adds queues to share (3000 frames, 3 workers: 18.0 ms with one group each, 19-22 ms with two).  Read by icsp_create.
-    if (nworker > ndev) setenv("ICSP_P_GROUPS", "1", 0);
-    // An all-intra batch in two parts only pays when the same resident range is encoded again and again (a part then follows
-    // its own previous pass); every chunk here is encoded once.
-    setenv("ICSP_I_GROUPS", "1", 0);
+    // adds queues to share (3000 frames, 3 workers: 18.0 ms with one group each, 19-22 ms with two).
+    // An all-intra batch in two parts only pays when several passes are in flight (a part then follows what its own stream
+    // carries); every chunk here is encoded once and waited for.  Both go to every context through icsp_set_groups (an
+    // environment variable set here, with the runtime's threads and the helper already running, would race with their getenv).
+    const int p_groups = nworker > ndev && !getenv("ICSP_P_GROUPS") ? 1 : 0, i_groups = getenv("ICSP_I_GROUPS") ? 0 : 1;
     chunk_gops = std::max(1, std::min(chunk_gops, (ngop + nworker - 1) / nworker));     // every worker gets something to do
     const int chunk = chunk_gops * L;
     std::vector<Chunk> chunks;
@@ -380,6 +380,7 @@ int main(int argc, char* argv[])
         double t0 = now();
         const int cmax = std::min(chunk, n);
         w->rc = icsp_create(&w->ctx, &params, w->device, cmax);
+        if (!w->rc) w->rc = icsp_set_groups(w->ctx, p_groups, i_groups);
         if (!w->rc) w->rc = icsp_prepare(w->ctx);
         if (!w->rc && shared_copies) w->rc = icsp_copy_streams(w->ctx, 1);
         if (w->rc) w->err = std::string(icsp_strerror(w->rc)) + ": " + (w->ctx ? icsp_last_error(w->ctx) : "");

@@ -32,7 +32,12 @@
  *   ICSP_INTRA_FORM 8|32 lanes per 8x8 block in the intra luma kernel: 32 = latency form (two blocks per wave), 8 = throughput
  *                        form (eight blocks per wave); default: 8 when there are more than 1.5 frames per CU or the frame is
  *                        wider than one round of the 32-lane form, else 32
+ *   ICSP_WHOLE     0|1   0: never place a range whole on one stream when the caller alternates between independent ranges
+ *                        (icsp_encode_resident); default 1
  *   ICSP_XCD_SLICES 0..64 bands a frame is cut into when a P step's workgroups are dealt over the XCDs (0 = automatic; rounded down to a power of two)
+ * Launch path: a failed kernel launch, event record or cross-stream wait could silently drop an ordering edge and yield
+ * wrong bits, so it POISONS the context: that call and every later call on the context return ICSP_ERR_HIP
+ * (icsp_last_error names the first failure) until icsp_destroy.
  * Threading: one context per device; calls on one context must be serialised by the caller; distinct
  * contexts are independent (the host GOP dispatcher uses one thread per GPU, the analogue of
  * encoding_thread, ENC:186-213).
@@ -81,7 +86,11 @@ int icsp_encode_gop(icsp_ctx_t* ctx, const uint8_t* yuv420_in, int n,
 /* ---- resident path (inputs already in HBM when the timed region starts) --------------------- */
 int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv420_in, int first_frame, int n);   /* H2D into slots [first, first+n) */
 /* Encode slots [first, first+n); first must be GOP aligned (first % intra_period == 0).  Asynchronous
- * on the context's stream. */
+ * on the context's streams.  Consecutive calls are ordered against each other only as far as the data require: a range
+ * disjoint from every range still in flight (the next chunk of a clip: closed GOPs are the reference's independent jobs,
+ * ENC:186-213), or the very same range again, starts without waiting for the earlier calls; a range that partly overlaps
+ * one in flight waits for everything.  Whatever reads results (icsp_sync, icsp_download, icsp_pack_*) or writes inputs
+ * (icsp_upload) waits for every encode issued before it. */
 int icsp_encode_resident(icsp_ctx_t* ctx, int first_frame, int n);
 int icsp_sync(icsp_ctx_t* ctx);
 int icsp_download(icsp_ctx_t* ctx, int first_frame, int n,
@@ -95,6 +104,10 @@ typedef struct {
     int max_frames, n_mb;
 } icsp_device_view_t;
 int icsp_device_view(icsp_ctx_t* ctx, icsp_device_view_t* out);
+/* Scheduling knobs of ONE context (the environment variables ICSP_P_GROUPS / ICSP_I_GROUPS set the defaults of every
+ * context of the process): GOP groups on separate streams (1..3) and parts of a large all-intra batch (1..2); 0 keeps the
+ * current value.  Results never depend on them. */
+int icsp_set_groups(icsp_ctx_t* ctx, int p_groups, int i_groups);
 
 /* ---- debug taps used by the parity tests (not part of the reference boundary) ---------------- */
 /* Raw motion vectors int8[n][nMB][2] (Reconstructedmv, ENC:2426) and chosen intra modes uint8[n][nMB][4]
@@ -104,6 +117,9 @@ int icsp_download_debug(icsp_ctx_t* ctx, int first_frame, int n, int8_t* mv, uin
  * double[n][nMB][6][64], row-major [v][u] (DCT_block output, ENC:2685-2749).  Costs 8x the level store. */
 int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
+/* Test hook, needs no device: a context shell in the state a failed launch-path call leaves behind (poisoned).  Every entry
+ * point answers ICSP_ERR_HIP on it without touching the runtime; release it with icsp_destroy. */
+int icsp_debug_poisoned_context(icsp_ctx_t** out);
 
 /* ---- per-kernel timing with HIP events on the launch stream ---------------------------------- */
 enum { ICSP_K_INTRA_LUMA = 0, ICSP_K_CHROMA_DC, ICSP_K_RESIDUAL, ICSP_K_ME, ICSP_K_FRAME_SERIAL, ICSP_K_PACK, ICSP_K_DECODE, ICSP_K_COUNT };

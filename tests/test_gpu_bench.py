@@ -33,7 +33,7 @@ def test_single_gpu_line():
     assert cb["kind"] in ("reference", "port") and cb["cores"] >= 1 and cb["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["psnr_y_db"] > 25 and d["ippp"]["value"] > 1e4
-    assert d["ranks_seen"] == 1 and all(d["parity"].values()) and len(d["parity"]) == 3
+    assert d["ranks_seen"] == 1 and all(d["parity"].values()) and len(d["parity"]) == 5
     # the 8-GPU workloads of BASELINE configs[3] and [4], here on one GPU, outputs checked against the reference / the oracle
     assert d["config4"]["frames"] == 3390 and d["config4"]["recon_equals_reference"] and d["config4"]["value"] > 1e4
     assert d["config4"]["all_intra_loaded"]["value"] > 1e4

@@ -1,0 +1,166 @@
+"""Encodes of independent ranges of ONE context are not ordered against each other (icsp_device.hip: flight_admit /
+encode_range): the next chunk of a clip -- closed GOPs and independent I frames are the reference's independent jobs,
+ICSP_Codec_Encoder_source.cpp:186-213 -- starts beside the one before it; the same range again follows its own previous
+pass stream by stream; a range that partly overlaps one in flight joins everything first.  No host synchronisation between
+the encodes below; every result is then compared with reference hashes (tests/golden/streams.json) or the oracle.
+Also: a zero-copy consumer on the context's stream (icsp_device_view) finds every GOP group's results ordered before it."""
+import ctypes as C
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from icspcodec_amd import capi, clipgen
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+W, H = 352, 288
+KEYS = ("levels", "acflag", "mpm", "mvd", "recon")
+NT = min(os.cpu_count() or 1, 64)
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "streams.json")))
+
+
+def _cmp(got, want, ctx=""):
+    for k in KEYS:
+        if not np.array_equal(got[k], want[k]):
+            bad = np.argwhere(got[k] != want[k])
+            raise AssertionError(f"{ctx}{k}: {len(bad)} mismatches, first at {bad[0].tolist()}")
+
+
+def _ref(name, n, q, period):
+    return next(s for s in GOLDEN if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == (name, n, q, period) and "bin_sha256" in s)
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.mark.parametrize("period,q,name_a,groups", [(0, 16, "foremanlike", 2), (0, 16, "foremanlike", 1), (10, 8, "stefanlike", 2), (10, 8, "stefanlike", 1)])
+def test_alternating_disjoint_ranges_without_a_sync(period, q, name_a, groups, monkeypatch):
+    """A, B, A, B ...: two resident 300-frame ranges of different content, the bench's regime.  A is the clip the reference
+    CLI was run on (recon and .bin hashes), B checked against the oracle."""
+    monkeypatch.setenv("ICSP_P_GROUPS", str(groups))
+    monkeypatch.setenv("ICSP_I_GROUPS", str(groups))
+    n = 300
+    a = clipgen.synth_clip(name_a, n)
+    b = clipgen.synth_clip("mobilelike", n, first_frame=40)
+    want_b = po.encode_sequence(b, W, H, q, q, period, nthreads=NT)
+    ref = _ref(name_a, n, q, period)
+    enc = capi.Encoder(W, H, q, q, period, max_frames=2 * n)
+    enc.upload(a, first=0)
+    enc.upload(b, first=n)
+    for _ in range(4):
+        enc.encode_resident(0, n)
+        enc.encode_resident(n, n)
+    got_a = enc.download(0, n)
+    assert _sha(got_a["recon"]) == ref["recon_sha256"]
+    assert _sha(enc.pack_bitstream(0, n)) == ref["bin_sha256"]
+    _cmp(enc.download(n, n), want_b, "B after A,B x4: ")
+    # a range that partly overlaps both (joins everything), then the two again, B first
+    enc.encode_resident(150 if period == 0 else 150, 300)
+    enc.encode_resident(n, n)
+    enc.encode_resident(0, n)
+    enc.encode_resident(n, n)
+    assert _sha(enc.download(0, n, what=("recon",))["recon"]) == ref["recon_sha256"]
+    _cmp(enc.download(n, n), want_b, "B after an overlapping range: ")
+    # new input in B's slots only, while A's pass is in flight: the upload must wait for B's readers, B's next pass for the upload
+    c = clipgen.synth_clip("tablelike", n, first_frame=7)
+    enc.encode_resident(0, n)
+    enc.encode_resident(n, n)
+    enc.upload(c, first=n)
+    enc.encode_resident(n, n)
+    enc.encode_resident(0, n)
+    enc.encode_resident(n, n)
+    _cmp(enc.download(n, n), po.encode_sequence(c, W, H, q, q, period, nthreads=NT), "B after new input: ")
+    assert _sha(enc.download(0, n, what=("recon",))["recon"]) == ref["recon_sha256"]
+    enc.close()
+
+
+@pytest.mark.parametrize("period,q", [(0, 16), (5, 8)])
+def test_three_ranges_in_rotation_change_streams(period, q):
+    """Three ranges over two chain streams: every range comes back on the other stream than its previous pass and has to wait
+    for that pass (ev_done).  Unequal sizes, so that the passes really are in flight together."""
+    sizes = [120, 35, 80]
+    firsts = [0, 120, 155]
+    clip = clipgen.synth_clip("hallmonitorlike", sum(sizes))
+    enc = capi.Encoder(W, H, q, q, period, max_frames=sum(sizes))
+    enc.upload(clip)
+    for rnd in range(5):
+        for f, s in zip(firsts, sizes):
+            enc.encode_resident(f, s)
+    got = enc.download(0, sum(sizes))
+    enc.close()
+    for f, s in zip(firsts, sizes):
+        _cmp({k: got[k][f: f + s] for k in KEYS}, po.encode_sequence(clip[f: f + s], W, H, q, q, period, nthreads=NT), f"range at {f}: ")
+
+
+@pytest.mark.parametrize("period,q", [(0, 16), (5, 8)])
+def test_more_disjoint_ranges_than_flight_records(period, q):
+    """Six ranges in rotation (the table holds four): the overflow path joins and starts over; ragged last range."""
+    L = max(period, 1)
+    sizes = [60, 45, 60, 50, 55, 33]
+    firsts = np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+    assert all(f % L == 0 for f in firsts)
+    total = sum(sizes)
+    clip = clipgen.synth_clip("coastguardlike", total)
+    enc = capi.Encoder(W, H, q, q, period, max_frames=total)
+    enc.upload(clip)
+    for rnd in range(3):
+        for f, s in zip(firsts, sizes):
+            enc.encode_resident(f, s)
+    got = enc.download(0, total)
+    enc.close()
+    for f, s in zip(firsts, sizes):
+        want = po.encode_sequence(clip[f: f + s], W, H, q, q, period, nthreads=NT)
+        _cmp({k: got[k][f: f + s] for k in KEYS}, want, f"range at {f}: ")
+
+
+def test_device_view_consumer_sees_every_gop_group(monkeypatch):
+    """after icsp_device_view an outside consumer enqueues on view.stream.  An IPPP encode of >= 8 GOPs
+    runs its P-step chains on two streams; the encode must end with those joined onto the view's stream.  The consumer here
+    is a plain hipMemcpyAsync on view.stream followed by a wait on that stream alone -- no icsp_sync, no icsp_download."""
+    monkeypatch.setenv("ICSP_P_GROUPS", "2")
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    n, period, q = 300, 10, 8
+    clip = clipgen.synth_clip("stefanlike", n)
+    want = po.encode_sequence(clip, W, H, q, q, period, nthreads=NT)
+    enc = capi.Encoder(W, H, q, q, period, max_frames=n)
+    enc.upload(clip)
+    view = enc.device_view()
+    rec = np.zeros((n, enc.fsz), np.uint8)
+    lv = np.zeros((n, enc.nmb, 6, 64), np.int16)
+    mvd = np.zeros((n, enc.nmb, 2), np.int8)
+    for rnd in range(3):
+        rec[:] = 0; lv[:] = 0; mvd[:] = 0
+        enc.encode_resident(0, n)
+        D2H = 2
+        assert hip.hipMemcpyAsync(rec.ctypes.data, view.recon, rec.nbytes, D2H, view.stream) == 0
+        assert hip.hipMemcpyAsync(lv.ctypes.data, view.levels, lv.nbytes, D2H, view.stream) == 0
+        assert hip.hipMemcpyAsync(mvd.ctypes.data, view.mvd, mvd.nbytes, D2H, view.stream) == 0
+        assert hip.hipStreamSynchronize(view.stream) == 0
+        assert np.array_equal(rec, want["recon"]), rnd
+        assert np.array_equal(lv, want["levels"]), rnd
+        assert np.array_equal(mvd, want["mvd"]), rnd
+    enc.close()
+
+
+def test_set_groups_per_context():
+    """icsp_set_groups: the per-context form of ICSP_P_GROUPS / ICSP_I_GROUPS (what icsp_enc uses); results do not change."""
+    n, period, q = 90, 10, 16
+    clip = clipgen.synth_clip("newslike", n)
+    want = po.encode_sequence(clip, W, H, q, q, period, nthreads=NT)
+    enc = capi.Encoder(W, H, q, q, period, max_frames=n)
+    enc.upload(clip)
+    for pg in (1, 2, 3, 2):
+        enc.encode_resident(0, n)                       # in flight while the knob changes
+        enc.set_groups(p_groups=pg)
+        enc.encode_resident(0, n)
+        enc.encode_resident(0, n)
+        _cmp(enc.download(0, n), want, f"p_groups={pg}: ")
+    with pytest.raises(capi.IcspError):
+        enc.set_groups(p_groups=4)
+    enc.close()

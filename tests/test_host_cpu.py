@@ -26,6 +26,58 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.icsp_kernel_name(0) == b"k_intra_luma"
 
 
+def test_poisoned_context_keeps_returning_hip_error():
+    """A failed launch-path call (kernel launch, event record, cross-stream wait) poisons its context: every later entry point
+    answers ICSP_ERR_HIP instead of running on with an ordering edge missing.  The hook builds a context in that state; no
+    call below may reach the HIP runtime (there is no device here)."""
+    import ctypes as C
+    lib = capi.load()
+    ctx = C.c_void_p()
+    assert lib.icsp_debug_poisoned_context(C.byref(ctx)) == 0 and ctx
+    ERR_HIP = 5
+    buf = np.zeros(352 * 288 * 3 // 2, np.uint8)
+    n64 = C.c_uint64(0)
+    ms, cnt = C.c_double(0), C.c_longlong(0)
+    view = capi.DeviceView()
+    vp = buf.ctypes.data_as(C.c_void_p)
+    calls = {
+        "icsp_sync": lambda: lib.icsp_sync(ctx),
+        "icsp_upload": lambda: lib.icsp_upload(ctx, vp, 0, 1),
+        "icsp_upload_sync": lambda: lib.icsp_upload_sync(ctx, vp, 0, 1),
+        "icsp_encode_resident": lambda: lib.icsp_encode_resident(ctx, 0, 1),
+        "icsp_encode_gop": lambda: lib.icsp_encode_gop(ctx, vp, 1, None, None, None, None, None),
+        "icsp_download": lambda: lib.icsp_download(ctx, 0, 1, None, None, None, None, vp),
+        "icsp_download_debug": lambda: lib.icsp_download_debug(ctx, 0, 1, None, None),
+        "icsp_decode_resident": lambda: lib.icsp_decode_resident(ctx, 0, 1),
+        "icsp_upload_syntax": lambda: lib.icsp_upload_syntax(ctx, 0, 1, vp, vp, vp),
+        "icsp_pack_count": lambda: lib.icsp_pack_count(ctx, 0, 1, C.byref(n64)),
+        "icsp_pack_into": lambda: lib.icsp_pack_into(ctx, 0, 1, 0, vp, buf.size),
+        "icsp_pack_bits": lambda: lib.icsp_pack_bits(ctx, 0, 1, vp, buf.size, C.byref(n64)),
+        "icsp_prepare": lambda: lib.icsp_prepare(ctx),
+        "icsp_host_warm": lambda: lib.icsp_host_warm(ctx, vp, 4096),
+        "icsp_copy_streams": lambda: lib.icsp_copy_streams(ctx, 1),
+        "icsp_set_groups": lambda: lib.icsp_set_groups(ctx, 1, 1),
+        "icsp_device_view": lambda: lib.icsp_device_view(ctx, C.byref(view)),
+        "icsp_debug_keep_coef": lambda: lib.icsp_debug_keep_coef(ctx, 1),
+        "icsp_download_coef": lambda: lib.icsp_download_coef(ctx, 0, 1, vp),
+        "icsp_profile_enable": lambda: lib.icsp_profile_enable(ctx, 1),
+        "icsp_profile_reset": lambda: lib.icsp_profile_reset(ctx),
+        "icsp_profile_get": lambda: lib.icsp_profile_get(ctx, 0, C.byref(ms), C.byref(cnt)),
+    }
+    for rnd in range(2):                                   # sticky: the second round answers the same
+        for name, f in calls.items():
+            assert f() == ERR_HIP, (name, rnd)
+    assert b"icsp_debug_poisoned_context" in lib.icsp_last_error(ctx)
+    assert lib.icsp_destroy(ctx) == 0
+
+
+def test_build_flags_turn_unchecked_hip_calls_into_errors():
+    """Every HIP return code is checked or explicitly discarded: the product build carries -Werror=unused-value (hipError_t is
+    [[nodiscard]])."""
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert '"-Werror=unused-value"' in src and "-Wno-unused-value" not in src
+
+
 def _one_mb_stream(period, lv, ac, mpm, mvd):
     return capi.write_bitstream(32, 32, 16, 16, period, lv, ac, mpm, mvd)
 

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Resident throughput with the caller rotating over R disjoint resident ranges of n frames each (what a streaming host issues;
+bench.py's regime is R = 2): alt_ranges.py [period qp n nranges passes].  Environment (ICSP_WHOLE, ICSP_P_GROUPS, ...) is echoed."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from icspcodec_amd import capi, clipgen
+period = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+qp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
+R = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+passes = int(sys.argv[5]) if len(sys.argv) > 5 else 200
+name = "stefanlike" if period else "foremanlike"
+enc = capi.Encoder(352, 288, qp, qp, period, max_frames=n * R)
+for r in range(R):
+    enc.upload(clipgen.synth_clip(name, n, first_frame=(r * n) % 600), first=r * n)
+for k in range(100):
+    enc.encode_resident((k % R) * n, n)
+enc.sync()
+best = 0
+for rep in range(3):
+    t0 = time.perf_counter()
+    for k in range(passes):
+        enc.encode_resident((k % R) * n, n)
+    enc.sync()
+    dt = (time.perf_counter() - t0) / passes
+    best = max(best, n / dt)
+print(f"period={period} qp={qp} n={n} ranges={R}: {best:10.0f} fps  ({n / best * 1e3:.4f} ms/step) env={ {k: v for k, v in os.environ.items() if k.startswith(('HIP_', 'ICSP_', 'GPU_'))} }")
+enc.close()
