@@ -344,6 +344,7 @@ struct icsp_ctx {
     int sticky;                       // ICSP_ERR_HIP once a call of the launch path has failed (HIPQ): the context is poisoned
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
     int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
+    int force_pipe;                   // ICSP_INTRA_PIPE: 0 / 1 forces the plain / pipelined variant of the 8-lane intra kernel (-1: chosen from the batch)
     int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
     int i_groups;                     // ICSP_I_GROUPS: parts an all-intra batch of more frames than CUs is launched in (1 or 2)
     int p_groups, prio_hi;            // GOP groups whose P-step chains run on separate streams (created on first use: a stream costs
@@ -741,9 +742,10 @@ int decode_range(icsp_ctx* ctx, int first, int n)
     return 0;
 }
 
-template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
+template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, bool pipe, hipStream_t st)
 {
-    hipLaunchKernelGGL((k_intra_luma8<NW>), dim3(G), dim3(NW * 64), 0, st, g, fs, b);
+    if (pipe) hipLaunchKernelGGL((k_intra_luma8<NW, true>), dim3(G), dim3(NW * 64), 0, st, g, fs, b);
+    else      hipLaunchKernelGGL((k_intra_luma8<NW, false>), dim3(G), dim3(NW * 64), 0, st, g, fs, b);
 }
 
 // G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
@@ -762,14 +764,18 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     if (!form) form = (2 * G_all > 3 * ctx->n_cu || need > 16) ? 8 : 32;    // measured crossover on CIF: about 1.5 frames per CU
     if (form == 8) {
         const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : need8;
-        if (nw <= 1)       launch_intra8<1>(g, fs, b, G, st);
-        else if (nw <= 2)  launch_intra8<2>(g, fs, b, G, st);
-        else if (nw <= 3)  launch_intra8<3>(g, fs, b, G, st);
-        else if (nw <= 4)  launch_intra8<4>(g, fs, b, G, st);
-        else if (nw <= 6)  launch_intra8<6>(g, fs, b, G, st);
-        else if (nw <= 8)  launch_intra8<8>(g, fs, b, G, st);
-        else if (nw <= 12) launch_intra8<12>(g, fs, b, G, st);
-        else               launch_intra8<16>(g, fs, b, G, st);
+        // the pipelined variant (source row fetched a task ahead, stores a task behind) from two frames per CU: measured on CIF
+        // 1000 frames 1.69 M -> 1.83 M frames/s, 3390 frames 1.82 M -> 1.91 M, 600 in flight level, a lone 300-frame launch 0.98 M
+        // -> 0.95 M (one frame per CU: the extra instructions sit on the critical path of the only wave of its SIMD)
+        const bool pipe = ctx->force_pipe >= 0 ? ctx->force_pipe != 0 : G_all >= 2 * ctx->n_cu;
+        if (nw <= 1)       launch_intra8<1>(g, fs, b, G, pipe, st);
+        else if (nw <= 2)  launch_intra8<2>(g, fs, b, G, pipe, st);
+        else if (nw <= 3)  launch_intra8<3>(g, fs, b, G, pipe, st);
+        else if (nw <= 4)  launch_intra8<4>(g, fs, b, G, pipe, st);
+        else if (nw <= 6)  launch_intra8<6>(g, fs, b, G, pipe, st);
+        else if (nw <= 8)  launch_intra8<8>(g, fs, b, G, pipe, st);
+        else if (nw <= 12) launch_intra8<12>(g, fs, b, G, pipe, st);
+        else               launch_intra8<16>(g, fs, b, G, pipe, st);
         return;
     }
     const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : (G_all > ctx->n_cu ? (need < 8 ? need : 8) : need);
@@ -950,7 +956,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
-    ctx->force_intra_nw = 0; ctx->force_intra_form = 0;
+    ctx->force_intra_nw = 0; ctx->force_intra_form = 0; ctx->force_pipe = -1;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured (300 CIF frames, period 10): 1 group 0.75 M frames/s, 2 groups 0.89 M, 3 groups -- a fourth
                                        // busy stream of the context -- 0.27 M, whatever the stream priorities and GPU_MAX_HW_QUEUES
@@ -958,7 +964,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) || !env_int("ICSP_I_GROUPS", 1, 2, &ctx->i_groups) ||
         !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
         (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32) ||
-        !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
+        !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices) || !env_int("ICSP_INTRA_PIPE", 0, 1, &ctx->force_pipe)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     ctx->no_fuse = no_fuse != 0;
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
     auto fail = [&](int code, const char* what, hipError_t e) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); icsp_destroy(ctx); return code; };
