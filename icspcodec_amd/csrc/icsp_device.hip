@@ -126,6 +126,7 @@ __device__ TlEntry g_tl[8 * 2 * 8192];
 struct Geo {
     int W, H, sw, sh, nmb, cols8, rows8, cw, ch;
     int qdc, qac;
+    int prio;                         // the serial kernel's chain waves raise their issue priority (ICSP_SERIAL_PRIO)
     uint32_t mdc, mac;                // floor(2^32/q) + 1: |t|/q == umulhi(|t|, m) for |t| < 2^16, q > 1
     uint32_t msw, mtpr;               // the same for sw and for the tiles per row (sw + 1) / 2: n / sw == umulhi(n, msw) for n < 2^16
     long long fsz;                    // bytes per frame = W*H*3/2
@@ -631,6 +632,9 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // them only).  So the I frames of the next pass, a latency-bound launch on a few CUs, run beside P steps 2.. of this one
     // -- or beside another range's P steps -- instead of in front of an idle chip.
     if (int rc = group_streams(ctx, NG)) return rc;
+    // (The I frames of two alternating ranges, latency-bound launches on a few CUs each, follow each other on stream2 and set
+    //  the pace of that regime.  Giving every other range's I frames a stream of their own -- a fourth busy stream of the
+    //  context -- was measured: 1.05 M -> 0.86 M frames/s, with GPU_MAX_HW_QUEUES=8 as well; see DESIGN.md, negative results.)
     if (same) { for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(s2, F->ev_p1[k], 0)); }
     else if (joined || !lazy || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }   // after what was queued on `stream` (uploads ...)
     {
@@ -936,6 +940,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     g.W = p->width; g.H = p->height; g.sw = g.W / 16; g.sh = g.H / 16; g.nmb = g.sw * g.sh;
     g.cols8 = 2 * g.sw; g.rows8 = 2 * g.sh; g.cw = g.W / 2; g.ch = g.H / 2;
     g.qdc = p->qp_dc; g.qac = p->qp_ac;
+    g.prio = 1;
     // magic = floor(2^32/q) + 1 (== ceil(2^32/q) unless q is a power of two): |t|/q == umulhi(|t|, magic) for |t| < 2^16, and
     // strictly above 2^32/q, which the signed form in the DC chains needs (a negative multiple of q must not divide exactly)
     g.mdc = (uint32_t)(0x100000000ull / (unsigned)g.qdc + 1);               // unused when q == 1 (would not fit 32 bits)
@@ -964,7 +969,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) || !env_int("ICSP_I_GROUPS", 1, 2, &ctx->i_groups) ||
         !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
         (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32) ||
-        !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices) || !env_int("ICSP_INTRA_PIPE", 0, 1, &ctx->force_pipe)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
+        !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices) || !env_int("ICSP_INTRA_PIPE", 0, 1, &ctx->force_pipe) ||
+        !env_int("ICSP_SERIAL_PRIO", 0, 1, &g.prio)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     ctx->no_fuse = no_fuse != 0;
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
     auto fail = [&](int code, const char* what, hipError_t e) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); icsp_destroy(ctx); return code; };
