@@ -22,7 +22,7 @@ SYMBOLS = [
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
     "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
     "icsp_bitstream_begin", "icsp_bitstream_header", "icsp_pack_count", "icsp_pack_into", "icsp_prepare", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free", "icsp_host_register", "icsp_host_unregister", "icsp_host_warm", "icsp_copy_streams", "icsp_upload_sync",
-    "icsp_set_groups", "icsp_debug_poisoned_context",
+    "icsp_set_groups", "icsp_single_stream", "icsp_debug_poisoned_context",
 ]
 KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode"]
 
@@ -90,6 +90,7 @@ def load() -> C.CDLL:
         lib.icsp_upload_syntax.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp]
         lib.icsp_decode_resident.argtypes = [vp, C.c_int, C.c_int]
         lib.icsp_set_groups.argtypes = [vp, C.c_int, C.c_int]
+        lib.icsp_single_stream.argtypes = [vp, C.c_int]
         lib.icsp_debug_poisoned_context.argtypes = [C.POINTER(vp)]
         _lib = lib
     return _lib
@@ -305,6 +306,10 @@ class Encoder:
     def set_groups(self, p_groups=0, i_groups=0):
         """GOP groups on separate streams / parts of a large all-intra batch for this context (icsp_set_groups; 0 keeps)."""
         self._chk(self.lib.icsp_set_groups(self.ctx, p_groups, i_groups), "icsp_set_groups")
+
+    def single_stream(self, on=True):
+        """Every kernel of the context on its one stream (icsp_single_stream)."""
+        self._chk(self.lib.icsp_single_stream(self.ctx, int(on)), "icsp_single_stream")
 
     def copy_streams(self, shared=True):
         """Uploads and downloads on the device's two shared transfer streams (icsp_copy_streams)."""

@@ -341,6 +341,7 @@ struct icsp_ctx {
     bool p_dirty;
     Flight flight[kMaxFlights];
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
+    bool single;                      // icsp_single_stream: every kernel on `stream`, no chroma stream, no group streams
     bool whole_ok;                    // ICSP_WHOLE=0: never place a range whole on one stream (comparison)
     int sticky;                       // ICSP_ERR_HIP once a call of the launch path has failed (HIPQ): the context is poisoned
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
@@ -348,6 +349,7 @@ struct icsp_ctx {
     int force_pipe;                   // ICSP_INTRA_PIPE: 0 / 1 forces the plain / pipelined variant of the 8-lane intra kernel (-1: chosen from the batch)
     int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
     int i_groups;                     // ICSP_I_GROUPS: parts an all-intra batch of more frames than CUs is launched in (1 or 2)
+    int prio_lo;
     int p_groups, prio_hi;            // GOP groups whose P-step chains run on separate streams (created on first use: a stream costs
                                       // milliseconds to create, and an all-intra encode never needs them)
     hipStream_t pstream[kMaxPGroups]; // [0] unused (group 0 runs on `stream`)
@@ -500,9 +502,19 @@ int join_all(icsp_ctx* ctx)
 int fork_all(icsp_ctx* ctx)
 {
     HIPQ(hipEventRecord(ctx->ev_fork, ctx->stream));
-    HIPQ(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+    if (ctx->stream2) HIPQ(hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
     for (int k = 1; k < kMaxPGroups; k++) if (ctx->pstream[k]) HIPQ(hipStreamWaitEvent(ctx->pstream[k], ctx->ev_fork, 0));
     ctx->st_ahead = false;
+    return 0;
+}
+
+// stream2 (I-frame chroma / all I-frame kernels) is created by the first encode or decode of a context that is not in
+// single-stream mode: a stream costs 10-25 ms of set-up on this runtime (a hardware queue + its 4 MB and 16 MB buffers)
+int second_stream(icsp_ctx* ctx)
+{
+    if (ctx->stream2 || ctx->single) return 0;
+    HIPCHK(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, ctx->prio_lo));
+    ctx->st_ahead = true;                               // ordered after nothing yet: the next encode forks
     return 0;
 }
 
@@ -563,7 +575,9 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     if (n == 0) return 0;
     DevBufs b = ctx->b;
     if (!ctx->keep_coef) b.coef = nullptr;
-    hipStream_t st = ctx->stream, s2 = ctx->stream2;
+    if (int rc = second_stream(ctx)) return rc;
+    const bool single = ctx->single;                   // everything on `stream`: no cross-stream ordering at all
+    hipStream_t st = ctx->stream, s2 = single ? ctx->stream : ctx->stream2;
     const int G = (n + L - 1) / L;
     const int cwgs = ((g.nmb + 3) / 4 + 3) / 4;                       // k_residual8 workgroups per frame, chroma waves only
     // GOP groups (L > 1): a P step is a chain of dependent kernels of which the serial one is latency-bound (one workgroup
@@ -574,11 +588,11 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // A caller that alternates between independent ranges (this call's range is not the previous call's and does not touch
     // it) gets every range WHOLE on one of the two chain streams, taking turns: two whole batches side by side keep twice the
     // frames in flight that the two halves of one batch do.
-    const bool whole = lazy && ctx->whole_ok && ctx->last_n > 0 && (first >= ctx->last_first + ctx->last_n || ctx->last_first >= first + n);
+    const bool whole = !single && lazy && ctx->whole_ok && ctx->last_n > 0 && (first >= ctx->last_first + ctx->last_n || ctx->last_first >= first + n);
     ctx->last_first = first; ctx->last_n = n;
     int NG = ctx->p_groups;
     if (NG > G / 4) NG = G / 4;                        // keep every group's launches wide enough to be worth splitting
-    if (NG < 1 || L == 1 || whole) NG = 1;
+    if (NG < 1 || L == 1 || whole || single) NG = 1;
     auto group_lo = [&](int k) { return (int)((long long)G * k / NG); };
     // Which ranges are in flight decides the ordering against earlier calls (flight_admit): the same range again, or a range
     // disjoint from all of them -- the next chunk of a clip, the reference's independent GOP jobs (ENC:186-213) -- is not
@@ -605,9 +619,9 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // long as its slowest workgroup.  Two launches on two streams (unequal parts, so that they do not fall into step), each
         // following only what its own stream carries, keep the early finishers busy: a part starts as soon as the part before
         // it on its stream is through (300 CIF frames: 0.94 M -> 1.04 M frames/s; 600: +1 %).
-        const int NGI = (G > ctx->n_cu && !whole) ? ctx->i_groups : 1;
+        const int NGI = (G > ctx->n_cu && !whole && !single) ? ctx->i_groups : 1;
         if (NGI > 1) { if (int rc = group_streams(ctx, NGI)) return rc; }
-        if (!same && (joined || !lazy || ctx->st_ahead)) { if (int rc = fork_all(ctx)) return rc; }
+        if (!single && !same && (joined || !lazy || ctx->st_ahead)) { if (int rc = fork_all(ctx)) return rc; }
         for (int k = 0; k < NGI; k++) {
             const int g0 = k == 0 ? 0 : 2 * G / 5, g1 = k + 1 == NGI ? G : 2 * G / 5;
             hipStream_t sk = chain_stream(k);
@@ -618,7 +632,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
         LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
-        ctx->s2_dirty = true;
+        if (!single) ctx->s2_dirty = true;
         if (NGI > 1 || (whole && F->sidx)) ctx->p_dirty = true;
         if (whole) { HIPQ(hipEventRecord(F->ev_done, chain_stream(0))); F->done_valid = true; }
         if (!lazy) { if (int rc = join_all(ctx)) return rc; }
@@ -635,7 +649,8 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // (The I frames of two alternating ranges, latency-bound launches on a few CUs each, follow each other on stream2 and set
     //  the pace of that regime.  Giving every other range's I frames a stream of their own -- a fourth busy stream of the
     //  context -- was measured: 1.05 M -> 0.86 M frames/s, with GPU_MAX_HW_QUEUES=8 as well; see DESIGN.md, negative results.)
-    if (same) { for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(s2, F->ev_p1[k], 0)); }
+    if (single) { /* one stream: stream order is the order */ }
+    else if (same) { for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(s2, F->ev_p1[k], 0)); }
     else if (joined || !lazy || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }   // after what was queued on `stream` (uploads ...)
     {
         FrameSel fs{ first, L, G };
@@ -643,8 +658,10 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         const int sc_ = xcd_slices(G, cwgs);
         LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2); });
-        HIPQ(hipEventRecord(ctx->ev_join, s2));
-        for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(chain_stream(k), ctx->ev_join, 0));
+        if (!single) {
+            HIPQ(hipEventRecord(ctx->ev_join, s2));
+            for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(chain_stream(k), ctx->ev_join, 0));
+        }
     }
     // every chain is ordered after stream2's work; `stream` itself is one of them unless the range went whole onto the group stream
     if (whole && F->sidx) ctx->s2_dirty = true; else ctx->s2_dirty = false;
@@ -708,7 +725,9 @@ int decode_range(icsp_ctx* ctx, int first, int n)
     if (n == 0) return 0;
     DevBufs b = ctx->b;
     b.coef = nullptr;
-    hipStream_t st = ctx->stream, s2 = ctx->stream2;
+    if (int rc = second_stream(ctx)) return rc;
+    const bool single = ctx->single;
+    hipStream_t st = ctx->stream, s2 = single ? ctx->stream : ctx->stream2;
     const int G = (n + L - 1) / L;
     if (int rc = join_all(ctx)) return rc;
     ctx->st_ahead = true;
@@ -717,8 +736,7 @@ int decode_range(icsp_ctx* ctx, int first, int n)
     });
     {
         FrameSel fs{ first, L, G };
-        HIPQ(hipEventRecord(ctx->ev_fork, st));
-        HIPQ(hipStreamWaitEvent(s2, ctx->ev_fork, 0));
+        if (!single) { HIPQ(hipEventRecord(ctx->ev_fork, st)); HIPQ(hipStreamWaitEvent(s2, ctx->ev_fork, 0)); }
         LT(ctx, ICSP_K_DECODE, st, [&] {
             const int diag = g.rows8 < g.cols8 ? g.rows8 : g.cols8;              // widest anti-diagonal, 2 blocks per wave
             const int need = (diag + 1) / 2;
@@ -732,8 +750,7 @@ int decode_range(icsp_ctx* ctx, int first, int n)
         });
         const long long nblk = (long long)G * g.nmb * 2;
         LT(ctx, ICSP_K_DECODE, s2, [&] { hipLaunchKernelGGL(k_dec_blocks, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, s2, g, fs, b, 4, 2, 0); });
-        HIPQ(hipEventRecord(ctx->ev_join, s2));
-        HIPQ(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        if (!single) { HIPQ(hipEventRecord(ctx->ev_join, s2)); HIPQ(hipStreamWaitEvent(st, ctx->ev_join, 0)); }
     }
     for (int i = 1; i < L; i++) {
         int Gi = 0;
@@ -958,7 +975,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
     ctx->p_dirty = false; ctx->sticky = 0;
     memset(ctx->flight, 0, sizeof(ctx->flight));
-    ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0;
+    ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
     ctx->force_intra_nw = 0; ctx->force_intra_form = 0; ctx->force_pipe = -1;
@@ -979,7 +996,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     int prio_lo = 0, prio_hi = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { (void)hipGetLastError(); prio_lo = prio_hi = 0; }
     if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
-    if ((e = hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio_lo)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
+    ctx->prio_lo = prio_lo;            // stream2 is created by the first encode / decode that uses it (second_stream)
     if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipFuncSetAttribute((const void*)k_dec_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)) != hipSuccess)
@@ -1018,7 +1035,9 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
         std::lock_guard<std::mutex> lock(m);
         if (device_id >= 64 || !loaded[device_id]) {
             MeTables t; build_me_tables(t);
-            if ((e = hipMemcpyToSymbol(HIP_SYMBOL(c_me), &t, sizeof(t))) != hipSuccess) return fail(ICSP_ERR_HIP, "hipMemcpyToSymbol", e);
+            // (on the context's stream: the plain call would make the runtime create its null stream's queue, 10 ms of set-up)
+            if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_me), &t, sizeof(t), 0, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
+                (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipMemcpyToSymbolAsync", e);
             if (device_id < 64) loaded[device_id] = true;
         }
     }
@@ -1441,6 +1460,19 @@ int icsp_set_groups(icsp_ctx_t* ctx, int p_groups, int i_groups)
     return ICSP_OK;
 }
 
+// Everything on the context's one stream: no chroma stream, no GOP-group streams, no cross-stream events.  For hosts that
+// encode one short batch (a stream costs 10-25 ms of set-up: icsp_enc on a clip of one chunk) or keep a device busy from
+// several contexts anyway.  Results never depend on it.
+int icsp_single_stream(icsp_ctx_t* ctx, int on)
+{
+    ENTER(ctx);
+    HIPCHK(hipSetDevice(ctx->device));
+    if (int rc = join_all(ctx)) return rc;
+    ctx->st_ahead = true;
+    ctx->single = on != 0;
+    return ICSP_OK;
+}
+
 int icsp_device_view(icsp_ctx_t* ctx, icsp_device_view_t* v)
 {
     ENTER(ctx);
@@ -1544,7 +1576,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->device = 0; ctx->max_frames = 1;
     memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
     memset(ctx->flight, 0, sizeof(ctx->flight));
-    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true;
+    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0;
     ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;

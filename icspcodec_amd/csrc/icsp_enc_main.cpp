@@ -162,6 +162,7 @@ struct Worker {
     uint8_t* stage_in;                                     //   its input half (null when the input file is mapped and pinned)
     int up_chunk, up_rc; bool up_done;                     // the upload this worker has handed to its device's uploader thread
     double t_setup, t_read, t_write, t_up, t_enc, t_count, t_turn, t_pack, t_down;
+    double t_create, t_prepare, t_copystreams, t_mapwait, t_stage, t_warm;     // the parts of t_setup
 };
 
 // One-shot gate: the helper thread opens it when the file mappings are settled, the main thread when the runtime is up.
@@ -293,7 +294,9 @@ int main(int argc, char* argv[])
     // then takes 10 ms in two runs of three (measured; eight of eight at 2.4 ms this way).  Long clips keep the engines, which
     // move their data about 10 % faster beside the kernels.  (Decided before the runtime starts; never overrides the caller.)
     if ((uint64_t)n * nmb <= (uint64_t)1024 * 396) setenv("HSA_ENABLE_SDMA", "0", 0);
+    const double t_hip0 = now();
     const int ndev_seen = icsp_device_count();                      // starts the HIP runtime
+    const double t_hip = now() - t_hip0;
     hip_up.set();
     const int ndev = ndev_seen > 0 ? ndev_seen : 1;
     // a chunk: whole GOPs, by default as many frames as hold 512 CIF frames' macroblocks (at least one GOP)
@@ -335,6 +338,7 @@ int main(int argc, char* argv[])
         Worker& w = workers[d];
         w.device = d % ndev; w.rc = 0; w.chunks = 0; w.ctx = nullptr; w.body = nullptr; w.body_cap = 0; w.stage = nullptr; w.stage_in = nullptr; w.up_chunk = -1; w.up_rc = 0; w.up_done = true;
         w.t_setup = w.t_read = w.t_write = w.t_up = w.t_enc = w.t_count = w.t_turn = w.t_pack = w.t_down = 0;
+        w.t_create = w.t_prepare = w.t_copystreams = w.t_mapwait = w.t_stage = w.t_warm = 0;
     }
 
     // --hostpack: bring levels/flags/vectors back and run the sequential writer on the host (kept for cross-checking).
@@ -381,10 +385,17 @@ int main(int argc, char* argv[])
         const int cmax = std::min(chunk, n);
         w->rc = icsp_create(&w->ctx, &params, w->device, cmax);
         if (!w->rc) w->rc = icsp_set_groups(w->ctx, p_groups, i_groups);
+        // one chunk in all: the clip is encoded in a few milliseconds, a second stream takes longer than that to create
+        if (!w->rc && nchunks == 1) w->rc = icsp_single_stream(w->ctx, 1);
+        w->t_create = now() - t0;
+        double t1 = now();
         if (!w->rc) w->rc = icsp_prepare(w->ctx);
+        w->t_prepare = now() - t1; t1 = now();
         if (!w->rc && shared_copies) w->rc = icsp_copy_streams(w->ctx, 1);
+        w->t_copystreams = now() - t1; t1 = now();
         if (w->rc) w->err = std::string(icsp_strerror(w->rc)) + ": " + (w->ctx ? icsp_last_error(w->ctx) : "");
         maps_settled.wait();
+        w->t_mapwait = now() - t1; t1 = now();
         // pinned staging (each allocation costs milliseconds) only for whichever side is not mapped
         const size_t cbytes = (fsz * cmax + 255) & ~(size_t)255;
         uint8_t* stage_in = nullptr; uint8_t* stage_out = nullptr;
@@ -406,6 +417,7 @@ int main(int argc, char* argv[])
             return w->body != nullptr;
         };
         if (!w->rc && !opt.hostpack && !bin_pinned && !need_body(std::max<size_t>(cbytes / 2, (size_t)1 << 20))) { w->rc = ICSP_ERR_MEM_ALLOC; w->err = "pinned host memory"; }
+        w->t_stage = now() - t1; t1 = now();
         // the first transfers from and into the newly pinned mappings can cost their hipMemcpyAsync calls milliseconds: spend
         // that now.  One frame read from the input mapping (into slot 0, which the first chunk overwrites); the slots' content
         // written into the output mapping; and, below, the black GOP's string into the .bin mapping, cleared again (the image
@@ -424,6 +436,7 @@ int main(int argc, char* argv[])
                 icsp_pack_into(w->ctx, 0, std::min(L, cmax), 0, bin_map + 14, bin_est - 14) == ICSP_OK)
                 memset(bin_map + 14, 0, (size_t)(b / 8) + 1);
         }
+        w->t_warm = now() - t1;
         w->t_setup = now() - t0;
         {   // every worker arrives here, failed or not; the last arrival ends "init"
             std::unique_lock<std::mutex> l(ready.m);
@@ -610,16 +623,22 @@ int main(int argc, char* argv[])
         printf("[icsp_enc]{\"frames\": %d, \"workers\": %d, \"devices\": %d, \"chunk_frames\": %d, \"chunks\": %d, \"chunks_packed_into_bin_mapping\": %d, "
                "\"input_mapped\": %s, \"output_mapped\": %s, \"bin_mapped\": %s, "
                "\"init_s\": %.4f, \"encode_s\": %.4f, \"bitstream_and_files_s\": %.4f, \"map_files_s\": %.4f, \"pin_mappings_s\": %.4f, "
+               "\"hip_start_s\": %.4f, \"setup_worker0\": {\"create_s\": %.4f, \"prepare_s\": %.4f, \"copy_streams_s\": %.4f, \"wait_for_mappings_s\": %.4f, "
+               "\"staging_alloc_s\": %.4f, \"warm_transfers_s\": %.4f}, "
                "\"max_worker_setup_s\": %.4f, \"worker0\": {\"chunks\": %d, \"read_s\": %.4f, \"upload_s\": %.4f, \"encode_call_s\": %.4f, \"pack_count_s\": %.4f, "
                "\"turn_wait_s\": %.4f, \"pack_s\": %.4f, \"download_s\": %.4f, \"write_s\": %.4f}, "
                "\"bin_finish_s\": %.4f, \"bin_truncate_s\": %.4f, \"bin_bytes\": %zu, \"e2e_fps_excl_init\": %.1f, \"e2e_fps_incl_init\": %.1f}\n",
                n, nworker, std::min(ndev, nworker), chunk, nchunks, ndirect, in_map ? "true" : "false", out_map ? "true" : "false", bin_pinned ? "true" : "false",
-               t_init_done - t_start, t_encoded - t_init_done, t_files - t_encoded, t_map, t_pin, su,
+               t_init_done - t_start, t_encoded - t_init_done, t_files - t_encoded, t_map, t_pin,
+               t_hip, w0.t_create, w0.t_prepare, w0.t_copystreams, w0.t_mapwait, w0.t_stage, w0.t_warm, su,
                w0.chunks, w0.t_read, w0.t_up, w0.t_enc, w0.t_count, w0.t_turn, w0.t_pack, w0.t_down, w0.t_write,
                t_fin, t_trunc, nbytes, n / (t_files - t_init_done), n / (t_files - t_start));
     }
-    // contexts and pinned buffers go last: tearing the runtime down is not part of producing the files
-    // (the mappings stay pinned until the process ends: unpinning and unmapping them is not part of producing the files either)
+    // The files are complete and closed.  Contexts, pinned buffers, mappings and the runtime itself are not torn down piece by
+    // piece (tens of milliseconds of unmapping and freeing that produce nothing): the process ends here and the kernel reclaims
+    // them.  ICSP_ENC_TEARDOWN=1 takes the long way (leak checkers, tests).
+    fflush(stdout);
+    if (!getenv("ICSP_ENC_TEARDOWN")) _exit(0);
     for (auto& w : workers) { icsp_host_free(w.stage); icsp_host_free(w.body); icsp_destroy(w.ctx); }
     return 0;
 }

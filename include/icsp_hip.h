@@ -110,6 +110,10 @@ int icsp_device_view(icsp_ctx_t* ctx, icsp_device_view_t* out);
  * context of the process): GOP groups on separate streams (1..3) and parts of a large all-intra batch (1..2); 0 keeps the
  * current value.  Results never depend on them. */
 int icsp_set_groups(icsp_ctx_t* ctx, int p_groups, int i_groups);
+/* on != 0: every kernel of the context on its one stream (no chroma stream, no GOP-group streams).  A stream costs 10-25 ms of
+ * set-up on this runtime, more than a short batch takes to encode; hosts that encode one chunk (icsp_enc on a short clip) or
+ * run several contexts per device use it.  Results never depend on it. */
+int icsp_single_stream(icsp_ctx_t* ctx, int on);
 
 /* ---- debug taps used by the parity tests (not part of the reference boundary) ---------------- */
 /* Raw motion vectors int8[n][nMB][2] (Reconstructedmv, ENC:2426) and chosen intra modes uint8[n][nMB][4]

@@ -164,3 +164,30 @@ def test_set_groups_per_context():
     with pytest.raises(capi.IcspError):
         enc.set_groups(p_groups=4)
     enc.close()
+
+
+@pytest.mark.parametrize("period,q,n", [(0, 16, 300), (10, 8, 83), (3, 1, 20)])
+def test_single_stream_mode(period, q, n):
+    """icsp_single_stream: every kernel on the context's one stream (what icsp_enc uses on a clip of one chunk): encode, back-to-back
+    passes, another range, bit packer, decoder; then back to several streams in the same context."""
+    clip = clipgen.synth_clip("containerlike", n)
+    want = po.encode_sequence(clip, W, H, q, q, period, nthreads=NT)
+    enc = capi.Encoder(W, H, q, q, period, max_frames=n)
+    enc.single_stream(True)
+    enc.upload(clip)
+    enc.encode_resident(0, n)
+    enc.encode_resident(0, n)
+    L = max(period, 1)
+    if n > 2 * L:
+        enc.encode_resident(L, n - L)
+        enc.encode_resident(0, L)
+    _cmp(enc.download(0, n), want, "single stream: ")
+    assert enc.pack_bitstream(0, n) == capi.write_bitstream(W, H, q, q, period, want["levels"], want["acflag"], want["mpm"], want["mvd"])
+    enc.decode_resident(0, n)
+    dec = enc.download(0, n, what=("recon",))["recon"]
+    assert np.array_equal(dec, po.decode_sequence(want["levels"], want["mpm"], want["mvd"], W, H, q, q, period))
+    enc.single_stream(False)
+    enc.encode_resident(0, n)
+    enc.encode_resident(0, n)
+    _cmp(enc.download(0, n), want, "several streams again: ")
+    enc.close()
