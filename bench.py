@@ -249,6 +249,7 @@ def main():
     enc.upload(clip, first=0)
     enc.upload(clip_b, first=NFRAMES)
     dt, prof, (ms_ai, n_ai) = timed(enc, NFRAMES, a.steps, a.warmup, "k_intra_luma")
+    choice_ai = enc.last_choice()
     recon = enc.download(0, NFRAMES, what=("recon",))["recon"]
     recon_b = enc.download(NFRAMES, NFRAMES, what=("recon",))["recon"]
     iso_ai = isolated_pass_ms(enc, NFRAMES)
@@ -315,6 +316,7 @@ def main():
         enc2.upload(clip2_b, first=NFRAMES)
         steps2 = max(2, a.steps)
         dt2, prof2, _ = timed(enc2, NFRAMES, steps2, a.warmup, None)      # no events inside this timed region
+        choice_ip = enc2.last_choice()
         recon2 = enc2.download(0, NFRAMES, what=("recon",))["recon"]
         recon2_b = enc2.download(NFRAMES, NFRAMES, what=("recon",))["recon"]
         iso_ip = isolated_pass_ms(enc2, NFRAMES)
@@ -353,6 +355,7 @@ def main():
                 "unit": "frames/s", "ms_per_step": round(dt2 / steps2 * 1e3, 4), "psnr_y_db": round(psnr_ip, 4),
                 "isolated_pass": {"ms": round(iso_ip, 4), "fps": round(NFRAMES / iso_ip * 1e3, 1),
                                   "note": "one pass, host waits before and after: nothing runs beside it"},
+                "regime": dict(choice_ip, gops_per_rank_per_step=NFRAMES // 10, frames_in_flight_per_cu=round(2 * NFRAMES / 256, 2)),
                 "read_roofline_frac": round(fps2 / world * read_mean_ip / 1e9 / HBM_PEAK_GBS, 5),
                 "kernels_ms_per_step": {k: round(v[0], 4) for k, v in prof2.items() if v[1]},
                 "launches_per_step": {k: v[1] for k, v in prof2.items() if v[1]},
@@ -381,6 +384,8 @@ def main():
         enc4 = capi.Encoder(W, H, 16, 16, 10, device=local, max_frames=nloc)
         enc4.upload(batch)
         sec = timed_passes(enc4, nloc, 5)
+        choice4 = enc4.last_choice()
+        iso4 = isolated_pass_ms(enc4, nloc, reps=5)
         rec4 = enc4.download(0, nloc, what=("recon",))["recon"]
         ok4 = True
         if world == 1:        # whole clips on this rank: the reference CLI's recon hashes (tests/golden/streams.json)
@@ -399,13 +404,22 @@ def main():
         enc4i = capi.Encoder(W, H, 16, 16, 0, device=local, max_frames=nloc)
         enc4i.upload(batch)
         sec_i = timed_passes(enc4i, nloc, 5)
+        choice4i = enc4i.last_choice()
         enc4i.close()
         config4 = {"workload": "12 CIF clips (11 x 300 f + 1 x 90 f = 3390 frames, 339 closed GOPs), --intraPeriod 10, QP=16, one "
                                "batch sharded by GOP over the ranks (BASELINE configs[3])", "scaling": "strong",
                    "value": round(ntot / sec, 1), "unit": "frames/s", "ms_per_pass": round(sec * 1e3, 3), "frames": ntot,
                    "recon_equals_reference": bool(ok4),
+                   # what decides a rank's efficiency on the strong-scaling legs: how much of the batch it holds
+                   "regime": dict(choice4, gops_per_rank=len(mine), frames_per_rank=nloc, p_frames_per_step_per_cu=round(len(mine) / 256, 3),
+                                  i_frames_per_cu=round(len(mine) / 256, 3),
+                                  isolated_pass_ms_this_rank=round(iso4, 3), isolated_pass_fps_this_rank=round(nloc / iso4 * 1e3, 1),
+                                  note="fewer GOPs per rank = fewer frames per launch: from the loaded regime (339 GOPs on one GPU) "
+                                       "towards the latency regime of configs[2] (30 GOPs); a rank's own isolated pass is listed so that "
+                                       "an N-rank line explains its efficiency"),
                    "read_roofline_frac": round(ntot / sec * (BYTES_I_FRAME_READ + 9 * BYTES_P_FRAME_READ) / 10.0 / 1e9 / HBM_PEAK_GBS / world, 5),
                    "all_intra_loaded": {"value": round(ntot / sec_i, 1), "unit": "frames/s", "ms_per_pass": round(sec_i * 1e3, 3),
+                                        "regime": dict(choice4i, frames_per_rank=nloc, frames_per_cu=round(nloc / 256, 2)),
                                         "read_roofline_frac": round(ntot / sec_i * BYTES_I_FRAME_READ / 1e9 / HBM_PEAK_GBS / world, 5),
                                         "rw_roofline_frac": round(ntot / sec_i * BYTES_I_FRAME_TOTAL / 1e9 / HBM_PEAK_GBS / world, 5)}}
         del batch, rec4, parts, cache
@@ -436,6 +450,8 @@ def main():
         for g in range(g_n):
             enc5.upload(gops[srcs[(g_lo + g) % 4]], first=g * L5)
         sec5 = timed_passes(enc5, g_n * L5, 2)
+        choice5 = enc5.last_choice()
+        iso5 = isolated_pass_ms(enc5, g_n * L5, reps=3)
         # check (outside the timed region): one resident GOP of each distinct content against the oracle's GOP thread pool
         first_of = {}
         for g in range(g_n):
@@ -453,6 +469,8 @@ def main():
                                "the ranks (BASELINE configs[4]; 1080 is not a multiple of 16)", "scaling": "strong",
                    "value": round(n5 / sec5, 1), "unit": "frames/s", "ms_per_pass": round(sec5 * 1e3, 2), "frames": n5,
                    "cif_equivalent_fps": round(n5 / sec5 * (w5 * h5) / P, 1), "recon_equals_oracle": bool(ok5),
+                   "regime": dict(choice5, gops_per_rank=g_n, frames_per_rank=g_n * L5, macroblocks_per_p_step_per_cu=round(g_n * 8160 / 256, 1),
+                                  isolated_pass_ms_this_rank=round(iso5, 2), isolated_pass_fps_this_rank=round(g_n * L5 / iso5 * 1e3, 1)),
                    "read_roofline_frac": round(n5 / sec5 * rd5 / 1e9 / HBM_PEAK_GBS / world, 5)}
         del gops
 
@@ -580,6 +598,9 @@ def main():
         "cpu_baseline": cpu,
         "parity": parity,
         "kernels_ms_per_step": {k: round(v[0], 4) for k, v in prof.items() if v[1]},
+        "regime": dict(choice_ai, frames_in_flight_per_cu=round(2 * NFRAMES / 256, 2),
+                       note="two independent 300-frame batches in flight on two streams; no scaling curve over GPUs has been measured "
+                            "on hardware so far (the driver's multi-GPU node has not been available: SCALE_r01/r02 are skipped records)"),
         "isolated_pass": {"ms": round(iso_ai, 4), "fps_per_gpu": round(NFRAMES / iso_ai * 1e3, 1),
                           "note": "one pass at a time, the host waiting before and after each (includes a launch and a sync round trip); in "
                                   "the timed steps consecutive passes over independent batches run side by side (DESIGN.md section 4)"},

@@ -22,7 +22,9 @@ SYMBOLS = [
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
     "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
     "icsp_bitstream_begin", "icsp_bitstream_header", "icsp_pack_count", "icsp_pack_into", "icsp_prepare", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free", "icsp_host_register", "icsp_host_unregister", "icsp_host_warm", "icsp_copy_streams", "icsp_upload_sync",
-    "icsp_set_groups", "icsp_single_stream", "icsp_debug_poisoned_context",
+    "icsp_set_groups", "icsp_single_stream", "icsp_debug_poisoned_context", "icsp_debug_last_choice",
+    "icsp_device_pci_bus_id", "icsp_numa_node_of_pci", "icsp_device_numa_node", "icsp_numa_nodes", "icsp_numa_cpus", "icsp_parse_cpulist",
+    "icsp_bind_thread_to_node", "icsp_populate_here", "icsp_chunk_device",
 ]
 KERNELS = ["k_intra_luma", "k_chroma_dc", "k_residual", "k_me", "k_frame_serial", "k_pack", "k_decode"]
 
@@ -306,6 +308,13 @@ class Encoder:
     def set_groups(self, p_groups=0, i_groups=0):
         """GOP groups on separate streams / parts of a large all-intra batch for this context (icsp_set_groups; 0 keeps)."""
         self._chk(self.lib.icsp_set_groups(self.ctx, p_groups, i_groups), "icsp_set_groups")
+
+    def last_choice(self) -> dict:
+        """What the last encode_resident chose (icsp_debug_last_choice)."""
+        v = [C.c_int(0) for _ in range(5)]
+        self._chk(self.lib.icsp_debug_last_choice(self.ctx, *[C.byref(x) for x in v]), "icsp_debug_last_choice")
+        return {"intra_lanes_per_block": v[0].value, "intra_waves_per_workgroup": v[1].value, "intra_pipelined": bool(v[2].value),
+                "range_whole_on_one_stream": bool(v[3].value), "gop_groups": v[4].value}
 
     def single_stream(self, on=True):
         """Every kernel of the context on its one stream (icsp_single_stream)."""

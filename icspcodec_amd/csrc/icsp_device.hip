@@ -341,6 +341,7 @@ struct icsp_ctx {
     bool p_dirty;
     Flight flight[kMaxFlights];
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
+    int last_form, last_nw, last_pipe, last_whole, last_groups;     // what the last encode chose (icsp_debug_last_choice)
     bool single;                      // icsp_single_stream: every kernel on `stream`, no chroma stream, no group streams
     bool whole_ok;                    // ICSP_WHOLE=0: never place a range whole on one stream (comparison)
     int sticky;                       // ICSP_ERR_HIP once a call of the launch path has failed (HIPQ): the context is poisoned
@@ -598,6 +599,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // disjoint from all of them -- the next chunk of a clip, the reference's independent GOP jobs (ENC:186-213) -- is not
     // ordered against them at all; the chroma / group streams follow `stream` (fork) only when it carries something they must
     // wait for (an upload, a join).
+    ctx->last_whole = whole; ctx->last_groups = NG;
     Flight* F = nullptr;
     bool same = false, joined = false;
     if (int rc = flight_admit(ctx, first, n, lazy, whole, &F, &same, &joined)) return rc;
@@ -789,6 +791,7 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
         // 1000 frames 1.69 M -> 1.83 M frames/s, 3390 frames 1.82 M -> 1.91 M, 600 in flight level, a lone 300-frame launch 0.98 M
         // -> 0.95 M (one frame per CU: the extra instructions sit on the critical path of the only wave of its SIMD)
         const bool pipe = ctx->force_pipe >= 0 ? ctx->force_pipe != 0 : G_all >= 2 * ctx->n_cu;
+        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_pipe = pipe;
         if (nw <= 1)       launch_intra8<1>(g, fs, b, G, pipe, st);
         else if (nw <= 2)  launch_intra8<2>(g, fs, b, G, pipe, st);
         else if (nw <= 3)  launch_intra8<3>(g, fs, b, G, pipe, st);
@@ -800,6 +803,7 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
         return;
     }
     const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : (G_all > ctx->n_cu ? (need < 8 ? need : 8) : need);
+    ctx->last_form = 32; ctx->last_nw = nw; ctx->last_pipe = 0;
     if (nw <= 2)       hipLaunchKernelGGL((k_intra_luma32<2, 1>), dim3(G), dim3(128), 0, st, g, fs, b);
     else if (nw <= 4)  hipLaunchKernelGGL((k_intra_luma32<4, 1>), dim3(G), dim3(256), 0, st, g, fs, b);
     else if (nw <= 6)  hipLaunchKernelGGL((k_intra_luma32<6, 3>), dim3(G), dim3(384), 0, st, g, fs, b);
@@ -976,6 +980,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->p_dirty = false; ctx->sticky = 0;
     memset(ctx->flight, 0, sizeof(ctx->flight));
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
+    ctx->last_form = ctx->last_nw = ctx->last_pipe = ctx->last_whole = ctx->last_groups = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
     ctx->force_intra_nw = 0; ctx->force_intra_form = 0; ctx->force_pipe = -1;
@@ -1471,6 +1476,36 @@ int icsp_single_stream(icsp_ctx_t* ctx, int on)
     ctx->st_ahead = true;
     ctx->single = on != 0;
     return ICSP_OK;
+}
+
+// What the last icsp_encode_resident chose (bench.py puts it beside its figures, so that a line explains its own regime):
+// form of the intra luma kernel (8 / 32 lanes per block), its waves per workgroup, pipelined variant or not, whether the range went
+// whole onto one chain stream, GOP groups.  Any pointer may be null.
+int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_pipelined, int* whole_range, int* gop_groups)
+{
+    ENTER(ctx);
+    if (intra_form) *intra_form = ctx->last_form;
+    if (intra_waves) *intra_waves = ctx->last_nw;
+    if (intra_pipelined) *intra_pipelined = ctx->last_pipe;
+    if (whole_range) *whole_range = ctx->last_whole;
+    if (gop_groups) *gop_groups = ctx->last_groups;
+    return ICSP_OK;
+}
+
+int icsp_device_pci_bus_id(int device, char* out, int cap)
+{
+    if (!out || cap < 13) return ICSP_ERR_RANGE;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { (void)hipGetLastError(); return ICSP_ERR_NO_DEVICE; }
+    if (hipDeviceGetPCIBusId(out, cap, device) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
+    return ICSP_OK;
+}
+
+int icsp_device_numa_node(int device)
+{
+    char id[32];
+    if (icsp_device_pci_bus_id(device, id, (int)sizeof(id)) != ICSP_OK) return -1;
+    return icsp_numa_node_of_pci(id);
 }
 
 int icsp_device_view(icsp_ctx_t* ctx, icsp_device_view_t* v)

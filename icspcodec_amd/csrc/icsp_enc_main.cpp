@@ -163,6 +163,7 @@ struct Worker {
     int up_chunk, up_rc; bool up_done;                     // the upload this worker has handed to its device's uploader thread
     double t_setup, t_read, t_write, t_up, t_enc, t_count, t_turn, t_pack, t_down;
     double t_create, t_prepare, t_copystreams, t_mapwait, t_stage, t_warm;     // the parts of t_setup
+    int node, bound;                                       // NUMA node of the worker's device (-1 unknown), whether the thread was bound to it
 };
 
 // One-shot gate: the helper thread opens it when the file mappings are settled, the main thread when the runtime is up.
@@ -261,12 +262,20 @@ int main(int argc, char* argv[])
     uint8_t* bin_map = nullptr;                                      // the .bin mapping (bin_cap bytes), pinned or not
     bool bin_pinned = false;                                         //   its first bin_est bytes are populated and pinned
     double t_map = 0, t_pin = 0;
-    Gate hip_up, maps_settled;
+    Gate hip_up, maps_settled, plan_ready;
+    // Placement (csrc/icsp_topology.cpp): on a host with several NUMA nodes a device's threads are bound to the node the device
+    // hangs off, and the pages of test_yuv.yuv that its chunks will be written into are allocated from a thread bound there
+    // (first touch) instead of all at once by MAP_POPULATE.  One node (every box this has run on so far): nothing changes.
+    const bool placement = icsp_numa_nodes() >= 2 && !getenv("ICSP_NO_PLACEMENT");
+    std::vector<int> dev_node;                                       // per device, filled once the runtime is up (before plan_ready)
+    std::vector<Chunk> chunks;
+    int ndev_used = 1;
+    size_t placed_bytes = 0;
     std::thread helper([&] {
         if (want_map) {
             const double t0 = now();
             void* out_raw = MAP_FAILED;
-            if (fd_rec >= 0) out_raw = mmap(nullptr, total_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_POPULATE, fd_rec, 0);
+            if (fd_rec >= 0) out_raw = mmap(nullptr, total_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | (placement ? 0 : MAP_POPULATE), fd_rec, 0);
             void* in_raw = mmap(nullptr, total_bytes, PROT_READ, MAP_SHARED | MAP_POPULATE, fd_in, 0);
             void* bin_raw = MAP_FAILED;
             if (ftruncate(fd_bin, (off_t)bin_cap) == 0) bin_raw = mmap(nullptr, bin_cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd_bin, 0);
@@ -274,6 +283,25 @@ int main(int argc, char* argv[])
                 for (size_t o = 0; o < bin_est; o += page) ((volatile uint8_t*)bin_raw)[o] = 0;      // (kernels before 5.14)
             t_map = now() - t0;
             hip_up.wait();
+            if (placement && out_raw != MAP_FAILED) {
+                // the chunk table and the devices' nodes are known now: one thread per device, bound to the device's node,
+                // touches the output pages of the device's chunks
+                plan_ready.wait();
+                const double tp = now();
+                std::vector<std::thread> th;
+                std::atomic<size_t> placed(0);
+                for (int d = 0; d < ndev_used; d++)
+                    th.emplace_back([&, d] {
+                        (void)icsp_bind_thread_to_node(dev_node[d], nullptr);
+                        for (size_t c = 0; c < chunks.size(); c++)
+                            if (icsp_chunk_device((int)c, ndev_used) == d &&
+                                icsp_populate_here((uint8_t*)out_raw + (size_t)chunks[c].first * fsz, (size_t)chunks[c].count * fsz) == ICSP_OK)
+                                placed += (size_t)chunks[c].count * fsz;
+                    });
+                for (auto& t : th) t.join();
+                placed_bytes = placed.load();
+                t_map += now() - tp;
+            }
             const double t1 = now();
             const bool pin = !opt.nopin;                          // --nopin: behave as if the runtime had refused every range
             if (pin && in_raw != MAP_FAILED && icsp_host_register(in_raw, total_bytes, 1) == ICSP_OK) in_map = (uint8_t*)in_raw;
@@ -320,7 +348,6 @@ int main(int argc, char* argv[])
     const int p_groups = nworker > ndev && !getenv("ICSP_P_GROUPS") ? 1 : 0, i_groups = getenv("ICSP_I_GROUPS") ? 0 : 1;
     chunk_gops = std::max(1, std::min(chunk_gops, (ngop + nworker - 1) / nworker));     // every worker gets something to do
     const int chunk = chunk_gops * L;
-    std::vector<Chunk> chunks;
     // The download side carries more than the upload side (reconstruction + bits) and sets the pace; it can start when the
     // first chunk has been uploaded, encoded and counted.  So with three chunks or more the first chunk of every device is a
     // quarter and the second a half of the rest (3000 CIF frames all-intra: 14.7 -> 14.3 ms).
@@ -333,12 +360,19 @@ int main(int argc, char* argv[])
         chunks.push_back(std::move(c));
     }
     const int nchunks = (int)chunks.size();
+    // Chunk c belongs to device c mod (devices in use): the devices advance through the clip together (a chunk's place in the
+    // bitstream is known when every chunk before it has reported its length) and each device's ranges are known in advance.
+    ndev_used = std::min(ndev, nworker);
+    dev_node.assign(ndev_used, -1);
+    if (placement) for (int d = 0; d < ndev_used; d++) dev_node[d] = icsp_device_numa_node(d);
+    plan_ready.set();
     std::vector<Worker> workers(nworker);
     for (int d = 0; d < nworker; d++) {
         Worker& w = workers[d];
         w.device = d % ndev; w.rc = 0; w.chunks = 0; w.ctx = nullptr; w.body = nullptr; w.body_cap = 0; w.stage = nullptr; w.stage_in = nullptr; w.up_chunk = -1; w.up_rc = 0; w.up_done = true;
         w.t_setup = w.t_read = w.t_write = w.t_up = w.t_enc = w.t_count = w.t_turn = w.t_pack = w.t_down = 0;
         w.t_create = w.t_prepare = w.t_copystreams = w.t_mapwait = w.t_stage = w.t_warm = 0;
+        w.node = -1; w.bound = 0;
     }
 
     // --hostpack: bring levels/flags/vectors back and run the sequential writer on the host (kept for cross-checking).
@@ -348,7 +382,14 @@ int main(int argc, char* argv[])
     if (opt.hostpack) { levels.resize(nmb * 384 * n); acflag.resize(nmb * 6 * n); mpm.resize(nmb * 4 * n); mvd.resize(nmb * 2 * n); }
     Barrier ready; ready.total = nworker;
     Cursor cursor;
-    std::atomic<int> next_chunk(0);
+    // per device: how many of ITS chunks have been taken; the k-th chunk of device d is chunk d + k * ndev_used
+    std::vector<std::atomic<int>> next_on(ndev_used);
+    for (auto& a : next_on) a.store(0);
+    auto take_chunk = [&](int device) {
+        const int d = device % ndev_used;
+        const long long c = (long long)d + (long long)next_on[d].fetch_add(1) * ndev_used;
+        return c < nchunks ? (int)c : nchunks;
+    };
     // Several workers on a device: their uploads go through one stream of the device and their downloads through another
     // (icsp_copy_streams), so that the link carries both directions at once -- on their own streams all transfers of the device
     // end up on one DMA engine and run one at a time (3000 CIF frames: 18.6 ms = 1042 MB at the one-way rate; now 14-15 ms).
@@ -363,6 +404,7 @@ int main(int argc, char* argv[])
     struct Uploader { std::mutex m; std::condition_variable cv; std::deque<Worker*> q; bool stop = false; };
     std::vector<Uploader> uploaders(shared_copies ? ndev : 0);
     auto uploader_loop = [&](Uploader* u) {
+        if (placement) (void)icsp_bind_thread_to_node(dev_node[(int)(u - uploaders.data()) % ndev_used], nullptr);
         for (;;) {
             Worker* w;
             {
@@ -382,6 +424,7 @@ int main(int argc, char* argv[])
     };
     auto work = [&](Worker* w) {
         double t0 = now();
+        if (placement) { w->node = dev_node[w->device % ndev_used]; (void)icsp_bind_thread_to_node(w->node, &w->bound); }
         const int cmax = std::min(chunk, n);
         w->rc = icsp_create(&w->ctx, &params, w->device, cmax);
         if (!w->rc) w->rc = icsp_set_groups(w->ctx, p_groups, i_groups);
@@ -474,7 +517,7 @@ int main(int argc, char* argv[])
             return rc;
         };
         const bool early = shared_copies && !opt.hostpack;
-        int c = next_chunk.fetch_add(1);
+        int c = take_chunk(w->device);
         if (c < nchunks && !opt.hostpack) {
             int rc;
             if (early) { post_upload(c); rc = wait_upload(); } else rc = upload_here(c);
@@ -495,7 +538,7 @@ int main(int argc, char* argv[])
                                      mpm.data() + f * nmb * 4, mvd.data() + f * nmb * 2, rec);
                 w->t_enc += now() - t0;
                 if (rc) { fail(rc, nullptr); return; }
-                c2 = next_chunk.fetch_add(1);
+                c2 = take_chunk(w->device);
             } else {
                 t0 = now();
                 rc = icsp_encode_resident(w->ctx, 0, cn);
@@ -504,7 +547,7 @@ int main(int argc, char* argv[])
                 if (!rc) rc = icsp_pack_count(w->ctx, 0, cn, &bits);
                 w->t_count += now() - t0;
                 if (rc) { fail(rc, nullptr); return; }
-                c2 = next_chunk.fetch_add(1);
+                c2 = take_chunk(w->device);
                 if (early && c2 < nchunks) post_upload(c2);
                 t0 = now();
                 {   // my turn: every earlier chunk has reported its length
@@ -620,6 +663,8 @@ int main(int argc, char* argv[])
         double su = 0;
         for (auto& w : workers) su = std::max(su, w.t_setup);
         const Worker& w0 = workers[0];
+        int nbound = 0;
+        for (auto& w : workers) nbound += w.bound;
         printf("[icsp_enc]{\"frames\": %d, \"workers\": %d, \"devices\": %d, \"chunk_frames\": %d, \"chunks\": %d, \"chunks_packed_into_bin_mapping\": %d, "
                "\"input_mapped\": %s, \"output_mapped\": %s, \"bin_mapped\": %s, "
                "\"init_s\": %.4f, \"encode_s\": %.4f, \"bitstream_and_files_s\": %.4f, \"map_files_s\": %.4f, \"pin_mappings_s\": %.4f, "
@@ -627,11 +672,13 @@ int main(int argc, char* argv[])
                "\"staging_alloc_s\": %.4f, \"warm_transfers_s\": %.4f}, "
                "\"max_worker_setup_s\": %.4f, \"worker0\": {\"chunks\": %d, \"read_s\": %.4f, \"upload_s\": %.4f, \"encode_call_s\": %.4f, \"pack_count_s\": %.4f, "
                "\"turn_wait_s\": %.4f, \"pack_s\": %.4f, \"download_s\": %.4f, \"write_s\": %.4f}, "
+               "\"numa\": {\"nodes\": %d, \"placement\": %s, \"device0_node\": %d, \"threads_bound\": %d, \"output_bytes_placed\": %zu}, "
                "\"bin_finish_s\": %.4f, \"bin_truncate_s\": %.4f, \"bin_bytes\": %zu, \"e2e_fps_excl_init\": %.1f, \"e2e_fps_incl_init\": %.1f}\n",
                n, nworker, std::min(ndev, nworker), chunk, nchunks, ndirect, in_map ? "true" : "false", out_map ? "true" : "false", bin_pinned ? "true" : "false",
                t_init_done - t_start, t_encoded - t_init_done, t_files - t_encoded, t_map, t_pin,
                t_hip, w0.t_create, w0.t_prepare, w0.t_copystreams, w0.t_mapwait, w0.t_stage, w0.t_warm, su,
                w0.chunks, w0.t_read, w0.t_up, w0.t_enc, w0.t_count, w0.t_turn, w0.t_pack, w0.t_down, w0.t_write,
+               icsp_numa_nodes(), placement ? "true" : "false", dev_node.empty() ? -1 : dev_node[0], nbound, placed_bytes,
                t_fin, t_trunc, nbytes, n / (t_files - t_init_done), n / (t_files - t_start));
     }
     // The files are complete and closed.  Contexts, pinned buffers, mappings and the runtime itself are not torn down piece by

@@ -123,6 +123,9 @@ int icsp_download_debug(icsp_ctx_t* ctx, int first_frame, int n, int8_t* mv, uin
  * double[n][nMB][6][64], row-major [v][u] (DCT_block output, ENC:2685-2749).  Costs 8x the level store. */
 int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
+/* What the last icsp_encode_resident chose: intra luma kernel form (8 or 32 lanes per block), its waves per workgroup, pipelined
+ * variant (0/1), range placed whole on one chain stream (0/1), GOP groups.  Any pointer may be NULL.  For reports. */
+int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_pipelined, int* whole_range, int* gop_groups);
 /* Test hook, needs no device: a context shell in the state a failed launch-path call leaves behind (poisoned).  Every entry
  * point answers ICSP_ERR_HIP on it without touching the runtime; release it with icsp_destroy. */
 int icsp_debug_poisoned_context(icsp_ctx_t** out);
@@ -215,6 +218,21 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared);
  * all uploads of a device from ONE thread this way, one at a time, also keeps them on one DMA engine: a copy submitted while
  * the stream's engine is busy is given another engine, whose first use costs milliseconds. */
 int icsp_upload_sync(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n);
+
+/* ---- placement on multi-socket hosts (csrc/icsp_topology.cpp; host only, sysfs, no libnuma).  The reference's GOP thread pool
+ *      (ICSP_thread.cpp:39-77) places nothing; here frames move by DMA from and into pinned file mappings, so a device's host
+ *      threads and the pages of its chunks belong on the socket the device hangs off.  Every call is a no-op where there is
+ *      nothing to place (one node, unknown node, a container that forbids affinity changes). ---- */
+/* PCI bus id "dddd:bb:dd.f" of a HIP device (hipDeviceGetPCIBusId); ICSP_ERR_NO_DEVICE / ICSP_ERR_RANGE (cap too small). */
+int icsp_device_pci_bus_id(int device, char* out, int cap);
+int icsp_numa_node_of_pci(const char* bus_id);            /* /sys/bus/pci/devices/<id>/numa_node; -1 unknown */
+int icsp_device_numa_node(int device);                    /* the two above together; -1 unknown */
+int icsp_numa_nodes(void);                                /* nodes that have CPUs (>= 1) */
+int icsp_numa_cpus(int node, int* cpus, int cap);         /* CPUs of a node (count; cpus may be NULL); -1 no such node */
+int icsp_parse_cpulist(const char* list, int* cpus, int cap);   /* "0-3,8,10-11" -> cpus; count, -1 malformed */
+int icsp_bind_thread_to_node(int node, int* bound);      /* calling thread -> the node's CPUs; *bound: whether anything changed */
+int icsp_populate_here(void* p, size_t bytes);            /* first-touch the pages of a writable mapping from this thread */
+int icsp_chunk_device(int chunk, int ndev);               /* chunk -> device when a clip's chunks are dealt over ndev devices */
 
 /* ---- decoder side: DEC = /root/reference/source/decoder/ICSP_Codec_Decoder_source.cpp ---- */
 /* Host: readHeader (DEC:14-37).  intra_period is the header field as stored: 1 (or 0) = every frame intra (DEC.h:293). */
