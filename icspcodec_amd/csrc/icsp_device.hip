@@ -1207,8 +1207,9 @@ int icsp_decode_resident(icsp_ctx_t* ctx, int first, int n)
 
 // ---- device bit packer (icsp_pack.hip.inc).  Two steps: lengths + scans (the host learns the number of bits), then the
 // packing itself at a bit phase the host chooses.
-// bytes of body buffer for a string of `bits` bits: + the byte phase icsp_pack_into may place it at (< 64), + the dwords past
-// the end that k_pack_zero clears, rounded to a dword
+// bytes of body buffer for a string of `bits` bits placed at at0 = 8 * A + sh (A < 64 bytes of phase, sh < 8 bits: k_pack's at0
+// is at most 511): the string's bytes + 1 (bit phase) + 64 (byte phase) + the 16 bytes past the end that k_pack_zero may
+// clear, rounded up to a dword.  Invariant: at0 / 8 + ceil((sh + bits) / 8) + 16 <= pack_bytes(bits).
 static inline size_t pack_bytes(unsigned long long bits) { return ((size_t)(bits / 8) + 1 + 64 + 16 + 3) & ~(size_t)3; }
 
 static int pack_alloc(icsp_ctx* ctx)

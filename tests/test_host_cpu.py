@@ -217,3 +217,24 @@ def test_assemble_random_splits_and_parser_on_garbage():
             pass
     with pytest.raises(capi.IcspError):
         capi.parse_bitstream(b"\x00ICS", 1)
+
+
+def test_isa_guard_on_the_shipped_compile():
+    """build() disassembles the compile that ships (not only the -DICSP_NO_FMA one): fused multiply-adds per kernel must
+    equal the recorded table, the decoder kernels must hold none, and no kernel may spill to scratch."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    table = json.load(open(g.FMA_TABLE))
+    assert table and all("k_dec_" not in k for k in table)
+    meta = "- .agpr_count: 0\n    .name: {n}\n    .private_segment_fixed_size: {s}\n    .wavefront_size: 64\n"
+    kern = next(iter(table))
+    ok = "".join(f"{k}:\n" + "\tv_fmac_f64_e32 v[0:1], v[2:3], v[4:5]\n" * v + "\ts_endpgm\n" for k, v in table.items()) + \
+         "_ZN1xk_dec_blocksE:\n\tv_add_f64 v[0:1], v[0:1], v[2:3]\n\ts_endpgm\n" + "".join(meta.format(n=k, s=0) for k in table)
+    assert g.check_device_asm(ok)[kern] == table[kern]
+    with pytest.raises(RuntimeError, match="must be none"):
+        g.check_device_asm(ok.replace("v_add_f64 v[0:1], v[0:1], v[2:3]", "v_fma_f64 v[0:1], v[0:1], v[2:3], v[4:5]"))
+    with pytest.raises(RuntimeError, match="counts moved"):
+        g.check_device_asm(ok.replace(f"{kern}:\n", f"{kern}:\n\tv_fma_f64 v[0:1], v[0:1], v[2:3], v[4:5]\n", 1))
+    with pytest.raises(RuntimeError, match="scratch"):
+        g.check_device_asm(ok.replace(".private_segment_fixed_size: 0", ".private_segment_fixed_size: 28", 1))

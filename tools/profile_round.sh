@@ -3,7 +3,7 @@
 # passes (counters in runs of their own, the program directly after `--`), then the traffic calibration.  Output under
 # gpurun_out/$1/ ; tools/summarize_profiles.py condenses it into profiles/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
