@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libicsp_hip.so")
+LIB_PATH = os.environ.get("ICSP_LIB") or os.path.join(HERE, "libicsp_hip.so")      # ICSP_LIB: another build of the same ABI (A/B experiments)
 
 # every symbol include/icsp_hip.h declares
 SYMBOLS = [

@@ -765,10 +765,11 @@ int decode_range(icsp_ctx* ctx, int first, int n)
     return 0;
 }
 
+inline size_t intra8_lds_bytes(const Geo& g) { return (size_t)g.W + g.H + 8 * (size_t)(g.cols8 + 2); }     // neighbour state of one frame
 template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, bool pipe, hipStream_t st)
 {
-    if (pipe) hipLaunchKernelGGL((k_intra_luma8<NW, true>), dim3(G), dim3(NW * 64), 0, st, g, fs, b);
-    else      hipLaunchKernelGGL((k_intra_luma8<NW, false>), dim3(G), dim3(NW * 64), 0, st, g, fs, b);
+    if (pipe) hipLaunchKernelGGL((k_intra_luma8<NW, true>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+    else      hipLaunchKernelGGL((k_intra_luma8<NW, false>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
 }
 
 // G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
