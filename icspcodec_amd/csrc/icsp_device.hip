@@ -127,6 +127,7 @@ struct Geo {
     int W, H, sw, sh, nmb, cols8, rows8, cw, ch;
     int qdc, qac;
     int prio;                         // the serial kernel's chain waves raise their issue priority (ICSP_SERIAL_PRIO)
+    int bands;                        // tall frames: the DC chain's bands as waves of one continued wavefront (ICSP_SERIAL_BANDS)
     uint32_t mdc, mac;                // floor(2^32/q) + 1: |t|/q == umulhi(|t|, m) for |t| < 2^16, q > 1
     uint32_t msw, mtpr;               // the same for sw and for the tiles per row (sw + 1) / 2: n / sw == umulhi(n, msw) for n < 2^16
     long long fsz;                    // bytes per frame = W*H*3/2
@@ -962,7 +963,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     g.W = p->width; g.H = p->height; g.sw = g.W / 16; g.sh = g.H / 16; g.nmb = g.sw * g.sh;
     g.cols8 = 2 * g.sw; g.rows8 = 2 * g.sh; g.cw = g.W / 2; g.ch = g.H / 2;
     g.qdc = p->qp_dc; g.qac = p->qp_ac;
-    g.prio = 1;
+    g.prio = 1; g.bands = 1;
     // magic = floor(2^32/q) + 1 (== ceil(2^32/q) unless q is a power of two): |t|/q == umulhi(|t|, magic) for |t| < 2^16, and
     // strictly above 2^32/q, which the signed form in the DC chains needs (a negative multiple of q must not divide exactly)
     g.mdc = (uint32_t)(0x100000000ull / (unsigned)g.qdc + 1);               // unused when q == 1 (would not fit 32 bits)
@@ -993,7 +994,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
         !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
         (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32) ||
         !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices) || !env_int("ICSP_INTRA_PIPE", 0, 1, &ctx->force_pipe) ||
-        !env_int("ICSP_SERIAL_PRIO", 0, 1, &g.prio)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
+        !env_int("ICSP_SERIAL_PRIO", 0, 1, &g.prio) || !env_int("ICSP_SERIAL_BANDS", 0, 1, &g.bands)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     ctx->no_fuse = no_fuse != 0;
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
     auto fail = [&](int code, const char* what, hipError_t e) { ctx->err = std::string(what) + ": " + hipGetErrorString(e); icsp_destroy(ctx); return code; };

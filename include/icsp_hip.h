@@ -34,6 +34,7 @@
  *                        wider than one round of the 32-lane form, else 32
  *   ICSP_INTRA_PIPE 0|1  forces the plain / pipelined variant of the 8-lane intra kernel (default: pipelined from two frames per CU)
  *   ICSP_SERIAL_PRIO 0|1 1 (default): the DC-chain waves of the per-frame serial kernel run at raised issue priority
+ *   ICSP_SERIAL_BANDS 0|1 1 (default): frames taller than 512 lines run the bands of their DC chains as waves of one continued wavefront
  *   ICSP_WHOLE     0|1   0: never place a range whole on one stream when the caller alternates between independent ranges
  *                        (icsp_encode_resident); default 1
  *   ICSP_XCD_SLICES 0..64 bands a frame is cut into when a P step's workgroups are dealt over the XCDs (0 = automatic; rounded down to a power of two)

@@ -189,3 +189,23 @@ def test_back_to_back_passes_of_one_range_overlap(name, n, q, period, groups, mo
     enc.encode_resident(0, n)
     _cmp(enc.download(0, n), po.encode_sequence(other, W, H, q, q, period), "after an upload")
     enc.close()
+
+
+@pytest.mark.parametrize("w,h,q,name", [(240, 2304, 5, "tablelike"), (1920, 1088, 1, "mobilelike"), (2048, 1088, 16, "staticlike")])
+def test_tall_frames_dc_chain_bands_as_one_wavefront(w, h, q, name, monkeypatch):
+    """Frames taller than 512 lines with 2048 macroblocks or more: the bands of the P frames' DC chains run as waves of one
+    continued wavefront (dc_chain_band_wave: five luma and three chroma bands at 2304 lines, three and two at 1088), each waiting
+    on the band above through a progress word in LDS.  Against the oracle, and against the band-after-band form
+    (ICSP_SERIAL_BANDS=0).  DPCM_DC_block ENC:3822-3988, CDPCM_DC_block ENC:4420-4514."""
+    n = 4
+    clip = clipgen.synth_clip(name, 1, width=w, height=h).repeat(n, axis=0) if name == "staticlike" else clipgen.synth_clip(name, n, width=w, height=h)
+    want = po.encode_sequence(clip, w, h, q, q, 4, nthreads=NT)
+    for bands in ("1", "0"):
+        monkeypatch.setenv("ICSP_SERIAL_BANDS", bands)
+        enc = capi.Encoder(w, h, q, q, 4, max_frames=n)
+        enc.upload(clip)
+        for _ in range(3):
+            enc.encode_resident(0, n)
+        got = enc.download(0, n)
+        enc.close()
+        _cmp(got, want, f"{w}x{h} bands={bands}: ")
