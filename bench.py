@@ -345,7 +345,9 @@ def main():
             for mine, theirs in (("k_me", "k_me_false@"), ("k_residual", "k_residual8@"), ("k_frame_serial", "k_serial_fused@")):
                 for name, e in tk.items():
                     if name.startswith(theirs) and e.get("frames_per_launch", 15) == 15 and e.get("launches_seen", 0) >= 27 and mine in kr:
-                        kr[mine]["traffic_bytes_per_launch"] = e.get("hbm_bytes_per_launch")
+                        # (the counters are those of a 15-frame launch of the same kernel; a launch here carries frames_per_launch)
+                        if e.get("hbm_bytes_per_launch"):
+                            kr[mine]["traffic_bytes_per_launch"] = int(e["hbm_bytes_per_launch"] * kr[mine]["frames_per_launch"] / 15.0)
                         if "traffic_over_algorithmic" in e:
                             kr[mine]["traffic_over_algorithmic"] = e["traffic_over_algorithmic"]
         except Exception:
@@ -555,7 +557,9 @@ def main():
             traffic = None
     roof = {"bound": "hbm", "kernel": "k_intra_luma", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "traffic_is": "HBM-side bytes of the step's launches together (counters of one 300-frame launch of the same kernel, tools/pmc_workload.py)",
+            "traffic_is": "HBM-side bytes of one step's launch(es) of the kernel (rocprofv3 TCC counters of a 300-frame launch of the same kernel variant, "
+                          "tools/pmc_workload.py -> profiles/traffic.json)",
+            "traffic_over_algorithmic": round(traffic / (BYTES_INTRA_LUMA_KERNEL * NFRAMES), 3) if traffic else None,
             "launches_per_step": lps,
             "achieved_is": "chip level: the kernel's algorithmic bytes of one step (launches_per_step x algorithmic_bytes_per_launch) / "
                            "ms_per_step; launches of one step and of consecutive steps (independent batches) run side by side, so a "
@@ -567,22 +571,26 @@ def main():
             "whole_frame_read_frac": round(fps / world * BYTES_I_FRAME_READ / 1e9 / HBM_PEAK_GBS, 5),
             "whole_frame_rw_frac": round(fps / world * BYTES_I_FRAME_TOTAL / 1e9 / HBM_PEAK_GBS, 5),
             "limiter": "the contract's roofline is HBM; what actually limits this kernel is the 114-step dependency chain of a CIF "
-                       "frame and vector-instruction issue on the CUs that carry two frames (DESIGN.md §5), see fp64_valu_frac"}
+                       "frame: its waves wait (LDS round trips, step barrier: waiting_share_of_wave_cycles) more than they issue, with "
+                       "2.3 frames per CU in flight (DESIGN.md §5); see fp64_valu_frac / valu_issue_frac"}
     if pmc and kern_ms > 0:
-        # executed fp64 vector instructions (rocprofv3 SQ counters, profiles/) x 64 lanes / launch time vs the un-fused peak
+        # chip level, like `achieved`: the instructions of one step's launches (counters of one 300-frame launch of the same kernel
+        # x launches per step) over the step's share of the timed region
+        # executed fp64 vector instructions (rocprofv3 SQ counters, profiles/) x 64 lanes / time vs the un-fused peak
         ops = pmc.get("fp64_valu_insts_per_launch")
         if ops:
-            roof["fp64_valu_frac"] = round(ops * 64 / (kern_ms * 1e-3) / 1e9 / FP64_VALU_PEAK_GOPS, 4)
+            roof["fp64_valu_frac"] = round(ops * lps * 64 / (step_ms * 1e-3) / 1e9 / FP64_VALU_PEAK_GOPS, 4)
             roof["fp64_valu_peak_Gops"] = round(FP64_VALU_PEAK_GOPS, 1)
             roof["fp64_valu_source"] = pmc.get("source")
         # every vector instruction of a wave holds its SIMD's issue port for >= 4 cycles (measured: 4.0-4.5; conversions to and
         # from f64 7.2; tools/probe_issue.hip), so wave-instructions / (SIMDs x clock / 4) is the share of the chip's vector
-        # issue slots this launch fills.  Chip-wide figure; the 44 of 256 CUs that carry two of the 300 frames, and decide
-        # the launch time, run at about 2 x 256/300 x this / (1 - idle share) -- DESIGN.md section 5.
+        # issue slots the luma kernel fills (the chroma kernels of the step are not in it) -- DESIGN.md section 5.
         vi = pmc.get("valu_insts_per_launch")
         if vi:
             peak = 256 * 4 * 2.4e9 / 4                        # 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles at 2.4 GHz
-            roof["valu_issue_frac"] = round(vi / (kern_ms * 1e-3) / peak, 4)
+            roof["valu_issue_frac"] = round(vi * lps / (step_ms * 1e-3) / peak, 4)
+            roof["valu_insts_per_launch"] = int(vi)
+            roof["waiting_share_of_wave_cycles"] = pmc.get("waiting_share_of_wave_cycles")
             roof["valu_issue_peak_Ginst"] = round(peak / 1e9, 1)
     line = {
         "metric": "CIF encode fps, resident encode loop (all-intra QP=16; IPPP and the 8-GPU workloads alongside)", "value": round(fps, 1),
