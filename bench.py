@@ -148,6 +148,12 @@ def main():
     if "ICSP_BENCH_FORCE_DEVICE" in os.environ:
         local = int(os.environ["ICSP_BENCH_FORCE_DEVICE"])
     torch.cuda.set_device(local)
+    # this rank's host thread (and the threads it starts from here on) onto the NUMA node its GPU hangs off: a no-op on one node
+    _lib = capi.load()
+    import ctypes as _C
+    _bound = _C.c_int(0)
+    _node = _lib.icsp_device_numa_node(local)
+    _lib.icsp_bind_thread_to_node(_node, _C.byref(_bound))
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # nccl == RCCL on ROCm
@@ -606,7 +612,7 @@ def main():
         "cpu_baseline": cpu,
         "parity": parity,
         "kernels_ms_per_step": {k: round(v[0], 4) for k, v in prof.items() if v[1]},
-        "regime": dict(choice_ai, frames_in_flight_per_cu=round(2 * NFRAMES / 256, 2),
+        "regime": dict(choice_ai, frames_in_flight_per_cu=round(2 * NFRAMES / 256, 2), rank0_gpu_numa_node=_node, rank0_host_thread_bound=bool(_bound.value),
                        note="two independent 300-frame batches in flight on two streams; no scaling curve over GPUs has been measured "
                             "on hardware so far (the driver's multi-GPU node has not been available: SCALE_r01/r02 are skipped records)"),
         "isolated_pass": {"ms": round(iso_ai, 4), "fps_per_gpu": round(NFRAMES / iso_ai * 1e3, 1),
