@@ -343,6 +343,7 @@ struct icsp_ctx {
     Flight flight[kMaxFlights];
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
     int last_form, last_nw, last_pipe, last_whole, last_groups;     // what the last encode chose (icsp_debug_last_choice)
+    bool chroma_on_chain;             // ICSP_I_CHROMA_ON_CHAIN
     bool single;                      // icsp_single_stream: every kernel on `stream`, no chroma stream, no group streams
     bool whole_ok;                    // ICSP_WHOLE=0: never place a range whole on one stream (comparison)
     int sticky;                       // ICSP_ERR_HIP once a call of the launch path has failed (HIPQ): the context is poisoned
@@ -657,9 +658,13 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     else if (joined || !lazy || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }   // after what was queued on `stream` (uploads ...)
     {
         FrameSel fs{ first, L, G };
-        LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
+        // A range placed whole on one chain stream: its I frames' chroma kernels go in front of the chain instead of in front
+        // of the luma kernel -- stream2 sets the pace of the alternating regime (the ranges' luma wavefront kernels, 0.22 ms of
+        // latency each, follow each other there), and the chain stream has slack (ICSP_I_CHROMA_ON_CHAIN=0: as before).
+        hipStream_t scs = (whole && ctx->chroma_on_chain) ? chain_stream(0) : s2;
+        LT(ctx, ICSP_K_CHROMA_DC, scs, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, scs, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
-        LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
+        LT(ctx, ICSP_K_RESIDUAL, scs, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, scs, g, fs, b, 0, cwgs, sc_); });
         LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2); });
         if (!single) {
             HIPQ(hipEventRecord(ctx->ev_join, s2));
@@ -982,6 +987,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->p_dirty = false; ctx->sticky = 0;
     memset(ctx->flight, 0, sizeof(ctx->flight));
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
+    { int v_ = 1; if (!env_int("ICSP_I_CHROMA_ON_CHAIN", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_on_chain = v_ != 0; }
     ctx->last_form = ctx->last_nw = ctx->last_pipe = ctx->last_whole = ctx->last_groups = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
@@ -1614,7 +1620,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->device = 0; ctx->max_frames = 1;
     memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
     memset(ctx->flight, 0, sizeof(ctx->flight));
-    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0;
+    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true;
     ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
