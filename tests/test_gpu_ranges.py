@@ -191,3 +191,22 @@ def test_single_stream_mode(period, q, n):
     enc.encode_resident(0, n)
     _cmp(enc.download(0, n), want, "several streams again: ")
     enc.close()
+
+
+@pytest.mark.parametrize("period,q", [(0, 16), (10, 8)])
+def test_alternating_ranges_soak(period, q):
+    """A thousand encodes of two alternating ranges without a single host synchronisation, then both results: whatever ordering
+    edge were missing between passes on different streams would have many chances to show."""
+    n = 120
+    a = clipgen.synth_clip("childrenlike", n)
+    b = clipgen.synth_clip("tablelike", n, first_frame=11)
+    enc = capi.Encoder(W, H, q, q, period, max_frames=2 * n)
+    enc.upload(a, first=0)
+    enc.upload(b, first=n)
+    for _ in range(500):
+        enc.encode_resident(0, n)
+        enc.encode_resident(n, n)
+    got_a, got_b = enc.download(0, n), enc.download(n, n)
+    enc.close()
+    _cmp(got_a, po.encode_sequence(a, W, H, q, q, period, nthreads=NT), "A: ")
+    _cmp(got_b, po.encode_sequence(b, W, H, q, q, period, nthreads=NT), "B: ")
