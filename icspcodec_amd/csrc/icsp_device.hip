@@ -344,6 +344,7 @@ struct icsp_ctx {
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
     int last_form, last_nw, last_pipe, last_whole, last_groups;     // what the last encode chose (icsp_debug_last_choice)
     bool chroma_on_chain;             // ICSP_I_CHROMA_ON_CHAIN
+    bool intra_ring;                  // ICSP_INTRA_RING (default 1): the 8-lane intra kernel writes the reconstruction in 64-byte pieces through LDS
     bool single;                      // icsp_single_stream: every kernel on `stream`, no chroma stream, no group streams
     bool whole_ok;                    // ICSP_WHOLE=0: never place a range whole on one stream (comparison)
     int sticky;                       // ICSP_ERR_HIP once a call of the launch path has failed (HIPQ): the context is poisoned
@@ -772,10 +773,20 @@ int decode_range(icsp_ctx* ctx, int first, int n)
 }
 
 inline size_t intra8_lds_bytes(const Geo& g) { return (size_t)g.W + g.H + 8 * (size_t)(g.cols8 + 2); }     // neighbour state of one frame
-template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, bool pipe, hipStream_t st)
+// ring: the reconstruction goes out through LDS in 64-byte pieces (k_intra_luma8<.., RING>): every wavefront step has to fit one
+// round of the workgroup, and the ring (4 KB per wave) is kept to workgroups of at most eight waves
+template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, bool pipe, bool ring, hipStream_t st)
 {
-    if (pipe) hipLaunchKernelGGL((k_intra_luma8<NW, true>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
-    else      hipLaunchKernelGGL((k_intra_luma8<NW, false>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+    if constexpr (NW <= 8) {
+        if (ring) {
+            const size_t lds = intra8_lds_bytes(g) + (size_t)ring_slots(NW) * 64 * kRingBlocks;
+            if (pipe) hipLaunchKernelGGL((k_intra_luma8<NW, true, true>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+            else      hipLaunchKernelGGL((k_intra_luma8<NW, false, true>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+            return;
+        }
+    }
+    if (pipe) hipLaunchKernelGGL((k_intra_luma8<NW, true, false>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+    else      hipLaunchKernelGGL((k_intra_luma8<NW, false, false>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
 }
 
 // G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
@@ -798,15 +809,17 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
         // 1000 frames 1.69 M -> 1.83 M frames/s, 3390 frames 1.82 M -> 1.91 M, 600 in flight level, a lone 300-frame launch 0.98 M
         // -> 0.95 M (one frame per CU: the extra instructions sit on the critical path of the only wave of its SIMD)
         const bool pipe = ctx->force_pipe >= 0 ? ctx->force_pipe != 0 : G_all >= 2 * ctx->n_cu;
-        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_pipe = pipe;
-        if (nw <= 1)       launch_intra8<1>(g, fs, b, G, pipe, st);
-        else if (nw <= 2)  launch_intra8<2>(g, fs, b, G, pipe, st);
-        else if (nw <= 3)  launch_intra8<3>(g, fs, b, G, pipe, st);
-        else if (nw <= 4)  launch_intra8<4>(g, fs, b, G, pipe, st);
-        else if (nw <= 6)  launch_intra8<6>(g, fs, b, G, pipe, st);
-        else if (nw <= 8)  launch_intra8<8>(g, fs, b, G, pipe, st);
-        else if (nw <= 12) launch_intra8<12>(g, fs, b, G, pipe, st);
-        else               launch_intra8<16>(g, fs, b, G, pipe, st);
+        // (the template argument is >= nw, so "one round per step" holds for it when it holds for nw)
+        const bool ring = ctx->intra_ring && nw >= need8 && nw <= 8;
+        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_pipe = (pipe ? 1 : 0) | (ring ? 2 : 0);
+        if (nw <= 1)       launch_intra8<1>(g, fs, b, G, pipe, ring, st);
+        else if (nw <= 2)  launch_intra8<2>(g, fs, b, G, pipe, ring, st);
+        else if (nw <= 3)  launch_intra8<3>(g, fs, b, G, pipe, ring, st);
+        else if (nw <= 4)  launch_intra8<4>(g, fs, b, G, pipe, ring, st);
+        else if (nw <= 6)  launch_intra8<6>(g, fs, b, G, pipe, ring, st);
+        else if (nw <= 8)  launch_intra8<8>(g, fs, b, G, pipe, ring, st);
+        else if (nw <= 12) launch_intra8<12>(g, fs, b, G, pipe, false, st);
+        else               launch_intra8<16>(g, fs, b, G, pipe, false, st);
         return;
     }
     const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : (G_all > ctx->n_cu ? (need < 8 ? need : 8) : need);
@@ -988,6 +1001,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(ctx->flight, 0, sizeof(ctx->flight));
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
     { int v_ = 1; if (!env_int("ICSP_I_CHROMA_ON_CHAIN", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_on_chain = v_ != 0; }
+    { int v_ = 1; if (!env_int("ICSP_INTRA_RING", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->intra_ring = v_ != 0; }
     ctx->last_form = ctx->last_nw = ctx->last_pipe = ctx->last_whole = ctx->last_groups = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
@@ -1620,7 +1634,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->device = 0; ctx->max_frames = 1;
     memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
     memset(ctx->flight, 0, sizeof(ctx->flight));
-    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true;
+    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true; ctx->intra_ring = true;
     ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;

@@ -53,6 +53,25 @@ def test_forced_8_lane_form_matches_oracle(form8, name, n, qdc, qac, period, w, 
     assert np.array_equal(mode[0], dbg["mode"])
 
 
+@pytest.mark.parametrize("ring", ["0", "1"])
+@pytest.mark.parametrize("pipe", ["0", "1"])
+@pytest.mark.parametrize("w,h,n,period", [(352, 288, 3, 0), (48, 64, 4, 2), (80, 32, 3, 0), (112, 48, 3, 3), (144, 176, 2, 0), (704, 576, 2, 0)])
+def test_8_lane_form_variants(form8, ring, pipe, w, h, n, period):
+    """The four builds of the kernel -- stores a task behind or not (ICSP_INTRA_PIPE), reconstruction through the LDS ring or
+    straight out (ICSP_INTRA_RING) -- on widths whose last piece of a row is partial (6, 10, 14, 18 blocks) and full."""
+    os.environ["ICSP_INTRA_RING"], os.environ["ICSP_INTRA_PIPE"] = ring, pipe
+    try:
+        clip = clipgen.synth_clip("mobilelike", n, width=w, height=h)
+        enc = capi.Encoder(w, h, 8, 8, period, max_frames=n)
+        got = enc.encode(clip)
+        ch = enc.last_choice()
+        enc.close()
+    finally:
+        del os.environ["ICSP_INTRA_RING"], os.environ["ICSP_INTRA_PIPE"]
+    assert (ch["intra_lanes_per_block"], ch["intra_pipelined"], ch["intra_recon_ring"]) == (8, pipe == "1", ring == "1")
+    _cmp(got, po.encode_sequence(clip, w, h, 8, 8, period, nthreads=NT), f"{w}x{h} ring={ring} pipe={pipe}: ")
+
+
 @pytest.mark.parametrize("nw", ["1", "2", "16"])
 def test_8_lane_form_any_workgroup_width(form8, nw):
     """Fewer waves than the widest step needs (several rounds per step) and more than it needs (idle waves)."""
@@ -128,7 +147,7 @@ def test_all_intra_batch_in_two_parts_back_to_back(parts):
 
 
 @pytest.mark.parametrize("var,val", [("ICSP_I_GROUPS", "3"), ("ICSP_P_GROUPS", "0"), ("ICSP_NO_FUSE", "yes"), ("ICSP_INTRA_FORM", "16"),
-                                     ("ICSP_INTRA_NW", "17"), ("ICSP_XCD_SLICES", "-1"), ("ICSP_I_GROUPS", "")])
+                                     ("ICSP_INTRA_NW", "17"), ("ICSP_XCD_SLICES", "-1"), ("ICSP_I_GROUPS", ""), ("ICSP_INTRA_RING", "2")])
 def test_override_outside_its_range_fails_the_create(var, val):
     """include/icsp_hip.h: a tuning override that is not a whole number in its range makes icsp_create fail."""
     os.environ[var] = val
