@@ -21,6 +21,10 @@ done
 cd $R
 python3 tools/summarize_profiles.py $OUT $TAG > $OUT/summary.txt 2>&1
 tail -30 $OUT/summary.txt
+# the condensed files as made HERE, from this run alone (gpurun merges into gpurun_out/<tag>/ of the caller, where files of earlier
+# runs may still lie: summarising there again would average over them)
+mkdir -p $OUT/condensed
+cp profiles/${TAG}_kernel_stats_bench.csv profiles/${TAG}_bench_profiled.json profiles/traffic.json $OUT/condensed/
 # keep what is merged back small: the condensed files only
 rm -rf $OUT/stats/*/*_agent_info.csv
 find $OUT -name "*.csv" -size +8M -delete
