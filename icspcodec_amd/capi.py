@@ -313,7 +313,7 @@ class Encoder:
         """What the last encode_resident chose (icsp_debug_last_choice)."""
         v = [C.c_int(0) for _ in range(5)]
         self._chk(self.lib.icsp_debug_last_choice(self.ctx, *[C.byref(x) for x in v]), "icsp_debug_last_choice")
-        return {"intra_lanes_per_block": v[0].value, "intra_waves_per_workgroup": v[1].value, "intra_pipelined": bool(v[2].value & 1), "intra_recon_ring": bool(v[2].value & 2),
+        return {"intra_lanes_per_block": v[0].value, "intra_waves_per_workgroup": v[1].value, "intra_recon_ring": bool(v[2].value),
                 "range_whole_on_one_stream": bool(v[3].value), "gop_groups": v[4].value}
 
     def single_stream(self, on=True):

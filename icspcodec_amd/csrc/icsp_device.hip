@@ -342,7 +342,7 @@ struct icsp_ctx {
     bool p_dirty;
     Flight flight[kMaxFlights];
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
-    int last_form, last_nw, last_pipe, last_whole, last_groups;     // what the last encode chose (icsp_debug_last_choice)
+    int last_form, last_nw, last_ring, last_whole, last_groups;     // what the last encode chose (icsp_debug_last_choice)
     bool chroma_on_chain;             // ICSP_I_CHROMA_ON_CHAIN
     bool intra_ring;                  // ICSP_INTRA_RING (default 1): the 8-lane intra kernel writes the reconstruction in 64-byte pieces through LDS
     bool single;                      // icsp_single_stream: every kernel on `stream`, no chroma stream, no group streams
@@ -350,7 +350,6 @@ struct icsp_ctx {
     int sticky;                       // ICSP_ERR_HIP once a call of the launch path has failed (HIPQ): the context is poisoned
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
     int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
-    int force_pipe;                   // ICSP_INTRA_PIPE: 0 / 1 forces the plain / pipelined variant of the 8-lane intra kernel (-1: chosen from the batch)
     int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
     int i_groups;                     // ICSP_I_GROUPS: parts an all-intra batch of more frames than CUs is launched in (1 or 2)
     int prio_lo;
@@ -775,18 +774,16 @@ int decode_range(icsp_ctx* ctx, int first, int n)
 inline size_t intra8_lds_bytes(const Geo& g) { return (size_t)g.W + g.H + 8 * (size_t)(g.cols8 + 2); }     // neighbour state of one frame
 // ring: the reconstruction goes out through LDS in 64-byte pieces (k_intra_luma8<.., RING>): every wavefront step has to fit one
 // round of the workgroup, and the ring (4 KB per wave) is kept to workgroups of at most eight waves
-template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, bool pipe, bool ring, hipStream_t st)
+template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, bool ring, hipStream_t st)
 {
     if constexpr (NW <= 8) {
         if (ring) {
             const size_t lds = intra8_lds_bytes(g) + (size_t)ring_slots(NW) * 64 * kRingBlocks;
-            if (pipe) hipLaunchKernelGGL((k_intra_luma8<NW, true, true>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
-            else      hipLaunchKernelGGL((k_intra_luma8<NW, false, true>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+            hipLaunchKernelGGL((k_intra_luma8<NW, true>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
             return;
         }
     }
-    if (pipe) hipLaunchKernelGGL((k_intra_luma8<NW, true, false>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
-    else      hipLaunchKernelGGL((k_intra_luma8<NW, false, false>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+    hipLaunchKernelGGL((k_intra_luma8<NW, false>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
 }
 
 // G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
@@ -797,33 +794,31 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     // waves x 128 VGPRs so two workgroups share a CU and every frame of the batch is in flight at once (measured on
     // 300 CIF frames: 0.45 ms vs 0.57 ms).
     // 8-lane form (eight blocks per wave, k_intra_luma8): fewer instructions per block, more per wave and step.  It wins
-    // when the CUs are loaded anyway (more than about 1.5 frames per CU: 512 frames 1.43 M against 1.32 M frames/s, 400 frames
-    // level, 300 frames 0.89 M against 0.90 M) and on frames too wide for one round of the 32-lane form.
+    // when the CUs are loaded anyway -- from about 2.1 frames per CU (tools/sweep_intra.sh, CIF frames of one launch: 450 frames
+    // 1.22 M frames/s against 1.34 M for the 32-lane form, 512 frames 1.34 / 1.37 M, 600 frames 1.54 / 1.42 M, 1000 frames
+    // 1.92 / 1.46 M, 3390 frames 2.26 / 1.46 M; two 300-frame ranges in flight 1.44 / 1.43 M) -- and on frames too wide for one
+    // round of the 32-lane form.
     const int need = ctx->intra_waves;
     const int need8 = (need * 2 + 7) / 8;                           // waves of eight blocks for the widest step
     int form = ctx->force_intra_form;
-    if (!form) form = (2 * G_all > 3 * ctx->n_cu || need > 16) ? 8 : 32;    // measured crossover on CIF: about 1.5 frames per CU
+    if (!form) form = (10 * G_all > 21 * ctx->n_cu || need > 16) ? 8 : 32;
     if (form == 8) {
         const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : need8;
-        // the pipelined variant (source row fetched a task ahead, stores a task behind) from two frames per CU: measured on CIF
-        // 1000 frames 1.69 M -> 1.83 M frames/s, 3390 frames 1.82 M -> 1.91 M, 600 in flight level, a lone 300-frame launch 0.98 M
-        // -> 0.95 M (one frame per CU: the extra instructions sit on the critical path of the only wave of its SIMD)
-        const bool pipe = ctx->force_pipe >= 0 ? ctx->force_pipe != 0 : G_all >= 2 * ctx->n_cu;
         // (the template argument is >= nw, so "one round per step" holds for it when it holds for nw)
         const bool ring = ctx->intra_ring && nw >= need8 && nw <= 8;
-        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_pipe = (pipe ? 1 : 0) | (ring ? 2 : 0);
-        if (nw <= 1)       launch_intra8<1>(g, fs, b, G, pipe, ring, st);
-        else if (nw <= 2)  launch_intra8<2>(g, fs, b, G, pipe, ring, st);
-        else if (nw <= 3)  launch_intra8<3>(g, fs, b, G, pipe, ring, st);
-        else if (nw <= 4)  launch_intra8<4>(g, fs, b, G, pipe, ring, st);
-        else if (nw <= 6)  launch_intra8<6>(g, fs, b, G, pipe, ring, st);
-        else if (nw <= 8)  launch_intra8<8>(g, fs, b, G, pipe, ring, st);
-        else if (nw <= 12) launch_intra8<12>(g, fs, b, G, pipe, false, st);
-        else               launch_intra8<16>(g, fs, b, G, pipe, false, st);
+        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_ring = ring;
+        if (nw <= 1)       launch_intra8<1>(g, fs, b, G, ring, st);
+        else if (nw <= 2)  launch_intra8<2>(g, fs, b, G, ring, st);
+        else if (nw <= 3)  launch_intra8<3>(g, fs, b, G, ring, st);
+        else if (nw <= 4)  launch_intra8<4>(g, fs, b, G, ring, st);
+        else if (nw <= 6)  launch_intra8<6>(g, fs, b, G, ring, st);
+        else if (nw <= 8)  launch_intra8<8>(g, fs, b, G, ring, st);
+        else if (nw <= 12) launch_intra8<12>(g, fs, b, G, false, st);
+        else               launch_intra8<16>(g, fs, b, G, false, st);
         return;
     }
     const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : (G_all > ctx->n_cu ? (need < 8 ? need : 8) : need);
-    ctx->last_form = 32; ctx->last_nw = nw; ctx->last_pipe = 0;
+    ctx->last_form = 32; ctx->last_nw = nw; ctx->last_ring = false;
     if (nw <= 2)       hipLaunchKernelGGL((k_intra_luma32<2, 1>), dim3(G), dim3(128), 0, st, g, fs, b);
     else if (nw <= 4)  hipLaunchKernelGGL((k_intra_luma32<4, 1>), dim3(G), dim3(256), 0, st, g, fs, b);
     else if (nw <= 6)  hipLaunchKernelGGL((k_intra_luma32<6, 3>), dim3(G), dim3(384), 0, st, g, fs, b);
@@ -1002,10 +997,10 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
     { int v_ = 1; if (!env_int("ICSP_I_CHROMA_ON_CHAIN", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_on_chain = v_ != 0; }
     { int v_ = 1; if (!env_int("ICSP_INTRA_RING", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->intra_ring = v_ != 0; }
-    ctx->last_form = ctx->last_nw = ctx->last_pipe = ctx->last_whole = ctx->last_groups = 0;
+    ctx->last_form = ctx->last_nw = ctx->last_ring = ctx->last_whole = ctx->last_groups = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
-    ctx->force_intra_nw = 0; ctx->force_intra_form = 0; ctx->force_pipe = -1;
+    ctx->force_intra_nw = 0; ctx->force_intra_form = 0;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured (300 CIF frames, period 10): 1 group 0.75 M frames/s, 2 groups 0.89 M, 3 groups -- a fourth
                                        // busy stream of the context -- 0.27 M, whatever the stream priorities and GPU_MAX_HW_QUEUES
@@ -1013,7 +1008,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) || !env_int("ICSP_I_GROUPS", 1, 2, &ctx->i_groups) ||
         !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
         (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32) ||
-        !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices) || !env_int("ICSP_INTRA_PIPE", 0, 1, &ctx->force_pipe) ||
+        !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices) ||
         !env_int("ICSP_SERIAL_PRIO", 0, 1, &g.prio) || !env_int("ICSP_SERIAL_BANDS", 0, 1, &g.bands)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     ctx->no_fuse = no_fuse != 0;
     const size_t nf = (size_t)max_frames, nmb = (size_t)g.nmb;
@@ -1502,14 +1497,14 @@ int icsp_single_stream(icsp_ctx_t* ctx, int on)
 }
 
 // What the last icsp_encode_resident chose (bench.py puts it beside its figures, so that a line explains its own regime):
-// form of the intra luma kernel (8 / 32 lanes per block), its waves per workgroup, pipelined variant or not, whether the range went
+// form of the intra luma kernel (8 / 32 lanes per block), its waves per workgroup, reconstruction through the LDS ring or not, whether the range went
 // whole onto one chain stream, GOP groups.  Any pointer may be null.
-int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_pipelined, int* whole_range, int* gop_groups)
+int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups)
 {
     ENTER(ctx);
     if (intra_form) *intra_form = ctx->last_form;
     if (intra_waves) *intra_waves = ctx->last_nw;
-    if (intra_pipelined) *intra_pipelined = ctx->last_pipe;
+    if (intra_recon_ring) *intra_recon_ring = ctx->last_ring;
     if (whole_range) *whole_range = ctx->last_whole;
     if (gop_groups) *gop_groups = ctx->last_groups;
     return ICSP_OK;

@@ -30,9 +30,8 @@
  *   ICSP_INTRA_NW  1..16 waves per workgroup of the intra luma kernel (rounded up to a built variant; default: from the
  *                        frame width and the batch size)
  *   ICSP_INTRA_FORM 8|32 lanes per 8x8 block in the intra luma kernel: 32 = latency form (two blocks per wave), 8 = throughput
- *                        form (eight blocks per wave); default: 8 when there are more than 1.5 frames per CU or the frame is
+ *                        form (eight blocks per wave); default: 8 when there are more than 2.1 frames per CU or the frame is
  *                        wider than one round of the 32-lane form, else 32
- *   ICSP_INTRA_PIPE 0|1  forces the plain / pipelined variant of the 8-lane intra kernel (default: pipelined from two frames per CU)
  *   ICSP_INTRA_RING 0|1  8-lane intra kernel: reconstruction written in 32-byte runs through a ring in LDS (default 1) or as 8-byte
  *                        block rows straight from the lanes (0)
  *   ICSP_SERIAL_PRIO 0|1 1 (default): the DC-chain waves of the per-frame serial kernel run at raised issue priority
@@ -126,10 +125,10 @@ int icsp_download_debug(icsp_ctx_t* ctx, int first_frame, int n, int8_t* mv, uin
  * double[n][nMB][6][64], row-major [v][u] (DCT_block output, ENC:2685-2749).  Costs 8x the level store. */
 int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
-/* What the last icsp_encode_resident chose: intra luma kernel form (8 or 32 lanes per block), its waves per workgroup, variant
- * of the 8-lane form (bit 0: stores a task behind, bit 1: reconstruction through the LDS ring), range placed whole on one chain
- * stream (0/1), GOP groups.  Any pointer may be NULL.  For reports. */
-int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_pipelined, int* whole_range, int* gop_groups);
+/* What the last icsp_encode_resident chose: intra luma kernel form (8 or 32 lanes per block), its waves per workgroup, whether the
+ * 8-lane form wrote the reconstruction through its LDS ring (0/1), range placed whole on one chain stream (0/1), GOP groups.
+ * Any pointer may be NULL.  For reports. */
+int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups);
 /* Test hook, needs no device: a context shell in the state a failed launch-path call leaves behind (poisoned).  Every entry
  * point answers ICSP_ERR_HIP on it without touching the runtime; release it with icsp_destroy. */
 int icsp_debug_poisoned_context(icsp_ctx_t** out);

@@ -54,12 +54,11 @@ def test_forced_8_lane_form_matches_oracle(form8, name, n, qdc, qac, period, w, 
 
 
 @pytest.mark.parametrize("ring", ["0", "1"])
-@pytest.mark.parametrize("pipe", ["0", "1"])
 @pytest.mark.parametrize("w,h,n,period", [(352, 288, 3, 0), (48, 64, 4, 2), (80, 32, 3, 0), (112, 48, 3, 3), (144, 176, 2, 0), (704, 576, 2, 0)])
-def test_8_lane_form_variants(form8, ring, pipe, w, h, n, period):
-    """The four builds of the kernel -- stores a task behind or not (ICSP_INTRA_PIPE), reconstruction through the LDS ring or
-    straight out (ICSP_INTRA_RING) -- on widths whose last piece of a row is partial (6, 10, 14, 18 blocks) and full."""
-    os.environ["ICSP_INTRA_RING"], os.environ["ICSP_INTRA_PIPE"] = ring, pipe
+def test_8_lane_form_variants(form8, ring, w, h, n, period):
+    """The two builds of the kernel -- reconstruction through the LDS ring or straight out (ICSP_INTRA_RING) -- on widths whose
+    last piece of a row is partial (6, 10, 14, 18 blocks) and full."""
+    os.environ["ICSP_INTRA_RING"] = ring
     try:
         clip = clipgen.synth_clip("mobilelike", n, width=w, height=h)
         enc = capi.Encoder(w, h, 8, 8, period, max_frames=n)
@@ -67,9 +66,9 @@ def test_8_lane_form_variants(form8, ring, pipe, w, h, n, period):
         ch = enc.last_choice()
         enc.close()
     finally:
-        del os.environ["ICSP_INTRA_RING"], os.environ["ICSP_INTRA_PIPE"]
-    assert (ch["intra_lanes_per_block"], ch["intra_pipelined"], ch["intra_recon_ring"]) == (8, pipe == "1", ring == "1")
-    _cmp(got, po.encode_sequence(clip, w, h, 8, 8, period, nthreads=NT), f"{w}x{h} ring={ring} pipe={pipe}: ")
+        del os.environ["ICSP_INTRA_RING"]
+    assert (ch["intra_lanes_per_block"], ch["intra_recon_ring"]) == (8, ring == "1")
+    _cmp(got, po.encode_sequence(clip, w, h, 8, 8, period, nthreads=NT), f"{w}x{h} ring={ring}: ")
 
 
 @pytest.mark.parametrize("nw", ["1", "2", "16"])

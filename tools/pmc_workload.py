@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The workload of the rocprofv3 --pmc passes (counters are per dispatch, kernels are serialised by the profiler):
   * BASELINE configs[1] the way bench.py runs it: two resident 300-frame all-intra batches (QP 16) encoded in turn, which makes the
-    library place each batch whole on one stream and pick the luma kernel for 600 frames in flight (k_intra_luma8<3, pipelined>,
+    library place each batch whole on one stream and pick the luma kernel for 600 frames in flight (k_intra_luma8<3, ring>,
     one launch of 300 workgroups per batch) -- the dominant kernel of the bench line;
   * one 300-frame batch encoded again and again (ICSP_I_GROUPS=1: ONE launch of k_intra_luma32<8,4>, round 2's dominant kernel, kept
     for comparison);
