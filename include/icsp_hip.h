@@ -37,6 +37,8 @@
  *   ICSP_SERIAL_PRIO 0|1 1 (default): the DC-chain waves of the per-frame serial kernel run at raised issue priority
  *   ICSP_SERIAL_BANDS 0|1 1 (default): frames taller than 512 lines run the bands of their DC chains as waves of one continued wavefront
  *   ICSP_WHOLE     0|1   0: never place a range whole on one stream when the caller alternates between independent ranges
+ *   ICSP_I_CHROMA_ON_CHAIN 0|1  1 (default): a range placed whole takes its I frames' chroma kernels to the front of its own chain
+ *                        stream; 0: they stay on the second stream with the luma kernel
  *                        (icsp_encode_resident); default 1
  *   ICSP_XCD_SLICES 0..64 bands a frame is cut into when a P step's workgroups are dealt over the XCDs (0 = automatic; rounded down to a power of two)
  * Launch path: a failed kernel launch, event record or cross-stream wait could silently drop an ordering edge and yield
