@@ -109,6 +109,34 @@ __device__ unsigned long long g_diag[16];
 #define DIAG_BEGIN
 #endif
 
+#ifdef ICSP_DIAG8
+// Diagnostic build only (tools/diag_intra8.hip): per-phase shader cycles of wave 0 of one workgroup of k_intra_luma8
+#ifndef ICSP_DIAG_BLOCK
+#define ICSP_DIAG_BLOCK 0
+#endif
+__device__ unsigned long long g_diag8[20];
+struct Dg8 { unsigned long long t0, acc[14]; bool on; };
+#define DG8_DECL Dg8 dg8; dg8.t0 = 0; for (int z_ = 0; z_ < 14; z_++) dg8.acc[z_] = 0; dg8.on = (blockIdx.x == ICSP_DIAG_BLOCK && threadIdx.x < 64); \
+                 const unsigned long long dg8_rt0 = __builtin_amdgcn_s_memrealtime(), dg8_c0 = __builtin_amdgcn_s_memtime();
+#define DG8_START(d) if ((d).on) { __builtin_amdgcn_sched_barrier(0); (d).t0 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_sched_barrier(0); }
+// (waits for everything outstanding first: a phase is charged with the memory and LDS latency it started)
+#define DG8_STAMP(d, n) if ((d).on) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); (d).acc[n] += t_ - (d).t0; (d).t0 = t_; __builtin_amdgcn_sched_barrier(0); }
+#define DG8_END if (dg8.on && threadIdx.x == 0) { for (int z_ = 0; z_ < 14; z_++) g_diag8[z_] = dg8.acc[z_]; g_diag8[14] = __builtin_amdgcn_s_memrealtime() - dg8_rt0; g_diag8[15] = __builtin_amdgcn_s_memtime() - dg8_c0; }
+#define DG8_ARG , Dg8* dgp
+#define DG8_PASS , &dg8
+#define DG8_OFF , (Dg8*)nullptr
+#define DG8_IN(n) if (dgp) { DG8_STAMP(*dgp, n) }
+#else
+#define DG8_DECL
+#define DG8_START(d)
+#define DG8_STAMP(d, n)
+#define DG8_END
+#define DG8_ARG
+#define DG8_PASS
+#define DG8_OFF
+#define DG8_IN(n)
+#endif
+
 #ifdef ICSP_TIMELINE
 // Diagnostic build only (tools/timeline.hip): every workgroup of the P-step kernels logs (start, end) in 100 MHz
 // s_memrealtime ticks into a slot of its own (kernel, GOP group, block): no atomics, so the logging does not serialise the

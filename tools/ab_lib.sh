@@ -10,6 +10,7 @@ for lib in "$OTHER" ""; do
   ICSP_LIB=$lib python tools/alt_ranges.py 0 16 300 1 300
   ICSP_LIB=$lib python tools/alt_ranges.py 0 16 3390 1 30
   ICSP_LIB=$lib python tools/alt_ranges.py 10 8 300 2 300
+  ICSP_LIB=$lib python tools/alt_ranges.py 10 8 300 1 300
   ICSP_LIB=$lib python tools/alt_ranges.py 10 16 3390 1 30
 done
 done
