@@ -372,6 +372,9 @@ struct icsp_ctx {
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
     int last_form, last_nw, last_ring, last_whole, last_groups;     // what the last encode chose (icsp_debug_last_choice)
     bool chroma_on_chain;             // ICSP_I_CHROMA_ON_CHAIN
+    int chroma_cap;                   // ICSP_CHROMA_CAP: KB of LDS reserved (not used) by the all-intra chroma launch of a small range placed whole
+                                      // (encode_range), on top of k_residual8's 16.9 KB.  Default 60: 77 KB per workgroup -- one per CU beside up to
+                                      // three 21.7 KB workgroups of the 8-lane luma kernel, two on a CU without any.  0: nothing reserved
     bool intra_ring;                  // ICSP_INTRA_RING (default 1): the 8-lane intra kernel writes the reconstruction in 64-byte pieces through LDS
     bool single;                      // icsp_single_stream: every kernel on `stream`, no chroma stream, no group streams
     bool whole_ok;                    // ICSP_WHOLE=0: never place a range whole on one stream (comparison)
@@ -661,9 +664,23 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             // frames in flight at once (which decides the kernel form): whole placement -> another batch like this one beside it
             LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? 2 * G : G, sk); });
         }
-        LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
-        LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
+        // A range placed whole runs beside another range's luma launch, and with up to about 1.25 frames per CU its chroma launches
+        // have slack on the second stream (0.14 ms of kernels per 0.2 ms step at 300 frames).  Left to itself k_residual8 fills
+        // every CU with eight workgroups of four waves, and the luma workgroups of the next launch, which have to start together to
+        // end together, find the CUs full and land unevenly: luma launches of 415-525 us beside chroma against 385 us alone.
+        // Reserving LDS the kernel does not use caps it at ONE workgroup per CU while luma workgroups are resident (two on an empty
+        // CU) and always leaves room for three luma workgroups: k_residual8 78 -> 163 us, luma 418 -> 388 us, two alternating
+        // 300-frame batches 1.44 -> 1.51 M frames/s, three 1.40 -> 1.49 M.  With more frames per batch the capped kernel no longer
+        // fits the step (two batches of 400: 1.72 -> 1.51 M, of 600: 1.99 -> 1.69 M; a batch on its own, 3390 frames: 2.26 -> 2.01 M):
+        // there, and beside the 32-lane luma form (250 frames: 1.44 -> 1.31 M), nothing is reserved.
+        // (The capped launch takes 0.17 ms, and with the DC kernel in front of it (0.03 ms) the chroma stream is as busy as the step
+        //  is long.  A chroma stream of its own for the second chain's range does not help: the two capped launches then share
+        //  the one workgroup slot the reservation leaves per CU -- 0.25 ms each, 1.51 -> 1.43 M frames/s.)
+        const bool cap = whole && ctx->chroma_cap && ctx->last_form == 8 && 4 * G <= 5 * ctx->n_cu;
+        const size_t cap_lds = cap ? (size_t)ctx->chroma_cap * 1024 : 0;
+        LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
+        LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), cap_lds, s2, g, fs, b, 0, cwgs, sc_); });
         if (!single) ctx->s2_dirty = true;
         if (NGI > 1 || (whole && F->sidx)) ctx->p_dirty = true;
         if (whole) { HIPQ(hipEventRecord(F->ev_done, chain_stream(0))); F->done_valid = true; }
@@ -1025,6 +1042,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
     { int v_ = 1; if (!env_int("ICSP_I_CHROMA_ON_CHAIN", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_on_chain = v_ != 0; }
     { int v_ = 1; if (!env_int("ICSP_INTRA_RING", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->intra_ring = v_ != 0; }
+    { int v_ = 60; if (!env_int("ICSP_CHROMA_CAP", 0, 120, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_cap = v_; }
     ctx->last_form = ctx->last_nw = ctx->last_ring = ctx->last_whole = ctx->last_groups = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
@@ -1050,6 +1068,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipFuncSetAttribute((const void*)k_dec_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)) != hipSuccess)
+        return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
+    if ((e = hipFuncSetAttribute((const void*)k_residual8, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
     ctx->prio_hi = prio_hi;            // the streams of the additional GOP groups are created by the first P step that uses them
     // k_frame_serial stages a frame's block sums, vectors and states in dynamic LDS: 15 bytes per macroblock
@@ -1657,7 +1677,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->device = 0; ctx->max_frames = 1;
     memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
     memset(ctx->flight, 0, sizeof(ctx->flight));
-    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true; ctx->intra_ring = true;
+    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true; ctx->intra_ring = true; ctx->chroma_cap = 60;
     ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;

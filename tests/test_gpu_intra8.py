@@ -146,7 +146,7 @@ def test_all_intra_batch_in_two_parts_back_to_back(parts):
 
 
 @pytest.mark.parametrize("var,val", [("ICSP_I_GROUPS", "3"), ("ICSP_P_GROUPS", "0"), ("ICSP_NO_FUSE", "yes"), ("ICSP_INTRA_FORM", "16"),
-                                     ("ICSP_INTRA_NW", "17"), ("ICSP_XCD_SLICES", "-1"), ("ICSP_I_GROUPS", ""), ("ICSP_INTRA_RING", "2")])
+                                     ("ICSP_INTRA_NW", "17"), ("ICSP_XCD_SLICES", "-1"), ("ICSP_I_GROUPS", ""), ("ICSP_INTRA_RING", "2"), ("ICSP_CHROMA_CAP", "121")])
 def test_override_outside_its_range_fails_the_create(var, val):
     """include/icsp_hip.h: a tuning override that is not a whole number in its range makes icsp_create fail."""
     os.environ[var] = val

@@ -210,3 +210,26 @@ def test_alternating_ranges_soak(period, q):
     enc.close()
     _cmp(got_a, po.encode_sequence(a, W, H, q, q, period, nthreads=NT), "A: ")
     _cmp(got_b, po.encode_sequence(b, W, H, q, q, period, nthreads=NT), "B: ")
+
+
+@pytest.mark.parametrize("cap", ["0", "100"])
+def test_chroma_reservation_never_changes_results(cap, monkeypatch):
+    """ICSP_CHROMA_CAP: the all-intra chroma launch of a range placed whole reserves LDS it does not use (default 60 KB) to stay
+    at one workgroup per CU beside the other range's luma launch.  None (0) or another amount (100 KB): the same bytes."""
+    monkeypatch.setenv("ICSP_CHROMA_CAP", cap)
+    n = 300
+    a = clipgen.synth_clip("foremanlike", n)
+    b = clipgen.synth_clip("mobilelike", n, first_frame=40)
+    ref = _ref("foremanlike", n, 16, 0)
+    enc = capi.Encoder(W, H, 16, 16, 0, max_frames=2 * n)
+    enc.upload(a, first=0)
+    enc.upload(b, first=n)
+    for _ in range(3):
+        enc.encode_resident(0, n)
+        enc.encode_resident(n, n)
+    ch = enc.last_choice()
+    assert ch["range_whole_on_one_stream"] and ch["intra_lanes_per_block"] == 8
+    assert _sha(enc.download(0, n, what=("recon",))["recon"]) == ref["recon_sha256"]
+    assert _sha(enc.pack_bitstream(0, n)) == ref["bin_sha256"]
+    _cmp(enc.download(n, n), po.encode_sequence(b, W, H, 16, 16, 0, nthreads=NT), "B: ")
+    enc.close()
