@@ -665,22 +665,29 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? 2 * G : G, sk); });
         }
         const int sc_ = xcd_slices(G, cwgs);
-        // A range placed whole runs beside another range's luma launch, and with up to about 1.25 frames per CU its chroma launches
+        // A range placed whole runs beside another range's luma launch, and with up to about 1.4 frames per CU its chroma launches
         // have slack on the second stream (0.14 ms of kernels per 0.2 ms step at 300 frames).  Left to itself k_residual8 fills
         // every CU with eight workgroups of four waves, and the luma workgroups of the next launch, which have to start together to
         // end together, find the CUs full and land unevenly: luma launches of 415-525 us beside chroma against 385 us alone.
-        // Reserving LDS the kernel does not use caps it at ONE workgroup per CU while luma workgroups are resident (two on an empty
-        // CU) and always leaves room for three luma workgroups: k_residual8 78 -> 163 us, luma 418 -> 388 us, two alternating
-        // 300-frame batches 1.44 -> 1.51 M frames/s, three 1.40 -> 1.49 M.  With more frames per batch the capped kernel no longer
-        // fits the step (two batches of 400: 1.72 -> 1.51 M, of 600: 1.99 -> 1.69 M; a batch on its own, 3390 frames: 2.26 -> 2.01 M):
-        // there, and beside the 32-lane luma form (250 frames: 1.44 -> 1.31 M), nothing is reserved.
-        // (The capped launch takes 0.17 ms, and with the DC kernel in front of it (0.03 ms) the chroma stream is as busy as the step
-        //  is long.  A chroma stream of its own for the second chain's range does not help: the two capped launches then share
-        //  the one workgroup slot the reservation leaves per CU -- 0.25 ms each, 1.51 -> 1.43 M frames/s.)
-        const bool cap = whole && ctx->chroma_cap && ctx->last_form == 8 && 4 * G <= 5 * ctx->n_cu;
+        // So there the chroma blocks go to ONE workgroup per CU (k_chroma_residual_strided: n_cu workgroups, each every n_cu-th
+        // unit), which also RESERVES LDS it does not use -- 77 KB with the reservation: the dispatcher then cannot put two of
+        // them on a CU that holds luma workgroups, and room for three luma workgroups is always left.  Measured, two alternating
+        // 300-frame batches: plain 1.44 M frames/s; k_residual8 itself with the reservation (one workgroup per CU at a time, but
+        // a dispatch between any two) 1.51 M, its chroma launch 78 -> 165 us; strided with the reservation 1.57 M (0.13 ms, and
+        // the step is the luma chains' again); strided without it 1.44 M, two workgroups per CU 1.49 M.  Two batches of 280 / 320 /
+        // 350 frames: 1.38 -> 1.51, 1.50 -> 1.64, 1.59 -> 1.70 M; three batches of 300 in rotation 1.39 -> 1.52 M.  With more frames
+        // per batch the one-per-CU launch no longer fits the step (two batches of 400: 1.72 -> 1.52 M, of 600: 1.98 -> 1.61 M; a
+        // batch on its own, 3390 frames: 2.26 -> 2.01 M): there, and beside the 32-lane luma form (250 frames: 1.44 -> 1.31 M),
+        // the chroma launch is the plain one.
+        // (A chroma stream of its own for the second chain's range does not help: the two launches then share the one
+        //  workgroup slot per CU -- 0.25 ms each, 1.43 M frames/s.)
+        const bool cap = whole && ctx->chroma_cap && ctx->last_form == 8 && 8 * G <= 11 * ctx->n_cu;
         const size_t cap_lds = cap ? (size_t)ctx->chroma_cap * 1024 : 0;
         LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
-        LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), cap_lds, s2, g, fs, b, 0, cwgs, sc_); });
+        if (cap)    // one workgroup per CU, each taking every n_cu-th unit: no dispatch between a CU's units (0.165 -> 0.13 ms)
+            LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_chroma_residual_strided, dim3(ctx->n_cu), dim3(256), cap_lds, s2, g, fs, b, cwgs); });
+        else
+            LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         if (!single) ctx->s2_dirty = true;
         if (NGI > 1 || (whole && F->sidx)) ctx->p_dirty = true;
         if (whole) { HIPQ(hipEventRecord(F->ev_done, chain_stream(0))); F->done_valid = true; }
@@ -1070,6 +1077,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if ((e = hipFuncSetAttribute((const void*)k_dec_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
     if ((e = hipFuncSetAttribute((const void*)k_residual8, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess)
+        return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
+    if ((e = hipFuncSetAttribute((const void*)k_chroma_residual_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
     ctx->prio_hi = prio_hi;            // the streams of the additional GOP groups are created by the first P step that uses them
     // k_frame_serial stages a frame's block sums, vectors and states in dynamic LDS: 15 bytes per macroblock
