@@ -669,7 +669,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // have slack on the second stream (0.14 ms of kernels per 0.2 ms step at 300 frames).  Left to itself k_residual8 fills
         // every CU with eight workgroups of four waves, and the luma workgroups of the next launch, which have to start together to
         // end together, find the CUs full and land unevenly: luma launches of 415-525 us beside chroma against 385 us alone.
-        // So there the chroma blocks go to ONE workgroup per CU (k_chroma_residual_strided: n_cu workgroups, each every n_cu-th
+        // So there the chroma blocks go to ONE workgroup per CU (k_residual8_strided: n_cu workgroups, each every n_cu-th
         // unit), which also RESERVES LDS it does not use -- 77 KB with the reservation: the dispatcher then cannot put two of
         // them on a CU that holds luma workgroups, and room for three luma workgroups is always left.  Measured, two alternating
         // 300-frame batches: plain 1.44 M frames/s; k_residual8 itself with the reservation (one workgroup per CU at a time, but
@@ -685,7 +685,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         const size_t cap_lds = cap ? (size_t)ctx->chroma_cap * 1024 : 0;
         LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         if (cap)    // one workgroup per CU, each taking every n_cu-th unit: no dispatch between a CU's units (0.165 -> 0.13 ms)
-            LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_chroma_residual_strided, dim3(ctx->n_cu), dim3(256), cap_lds, s2, g, fs, b, cwgs); });
+            LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8_strided, dim3(ctx->n_cu), dim3(256), cap_lds, s2, g, fs, b, 0, cwgs); });
         else
             LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         if (!single) ctx->s2_dirty = true;
@@ -1078,7 +1078,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
     if ((e = hipFuncSetAttribute((const void*)k_residual8, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
-    if ((e = hipFuncSetAttribute((const void*)k_chroma_residual_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess)
+    if ((e = hipFuncSetAttribute((const void*)k_residual8_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
     ctx->prio_hi = prio_hi;            // the streams of the additional GOP groups are created by the first P step that uses them
     // k_frame_serial stages a frame's block sums, vectors and states in dynamic LDS: 15 bytes per macroblock
