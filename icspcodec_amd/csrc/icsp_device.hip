@@ -512,7 +512,7 @@ int intra_waves_needed(const Geo& g)
     return (widest + 1) / 2;
 }
 
-void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st);
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma = false);
 
 // Orders `stream` after everything queued on the context's other streams (chroma stream, GOP-group streams): called by whatever
 // reads results, uploads, decodes, or encodes a range that partly overlaps one in flight.  No range is "in flight" afterwards.
@@ -655,6 +655,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // following only what its own stream carries, keep the early finishers busy: a part starts as soon as the part before
         // it on its stream is through (300 CIF frames: 0.94 M -> 1.04 M frames/s; 600: +1 %).
         const int NGI = (G > ctx->n_cu && !whole && !single) ? ctx->i_groups : 1;
+        const bool cap_ok = whole && ctx->chroma_cap && 8 * G <= 11 * ctx->n_cu;     // the chroma launches may take the one-workgroup-per-CU form (below)
         if (NGI > 1) { if (int rc = group_streams(ctx, NGI)) return rc; }
         if (!single && !same && (joined || !lazy || ctx->st_ahead)) { if (int rc = fork_all(ctx)) return rc; }
         for (int k = 0; k < NGI; k++) {
@@ -662,7 +663,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             hipStream_t sk = chain_stream(k);
             FrameSel fk{ first + g0, L, g1 - g0 };
             // frames in flight at once (which decides the kernel form): whole placement -> another batch like this one beside it
-            LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? 2 * G : G, sk); });
+            LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? 2 * G : G, sk, cap_ok); });
         }
         const int sc_ = xcd_slices(G, cwgs);
         // A range placed whole runs beside another range's luma launch, and with up to about 1.4 frames per CU its chroma launches
@@ -681,7 +682,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // the chroma launch is the plain one.
         // (A chroma stream of its own for the second chain's range does not help: the two launches then share the one
         //  workgroup slot per CU -- 0.25 ms each, 1.43 M frames/s.)
-        const bool cap = whole && ctx->chroma_cap && ctx->last_form == 8 && 8 * G <= 11 * ctx->n_cu;
+        const bool cap = cap_ok && ctx->last_form == 8;
         const size_t cap_lds = cap ? (size_t)ctx->chroma_cap * 1024 : 0;
         LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         if (cap)    // one workgroup per CU, each taking every n_cu-th unit: no dispatch between a CU's units (0.165 -> 0.13 ms)
@@ -839,7 +840,8 @@ template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const Dev
 }
 
 // G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
-void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st)
+// light_chroma: the chroma launches beside this one are encode_range's one-workgroup-per-CU form
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma)
 {
     // 32-lane form: two blocks per wave.  `need` waves cover the widest wavefront step in one round.
     // With at most one I frame per CU the kernel is pure latency: use `need` waves.  With more frames than CUs, cap at 8
@@ -853,7 +855,9 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     const int need = ctx->intra_waves;
     const int need8 = (need * 2 + 7) / 8;                           // waves of eight blocks for the widest step
     int form = ctx->force_intra_form;
-    if (!form) form = (10 * G_all > 21 * ctx->n_cu || need > 16) ? 8 : 32;
+    // (beside the one-workgroup-per-CU chroma launch of a range placed whole the 8-lane form wins earlier, from 1.75 frames per CU:
+    //  two batches of 220 / 230 / 240 / 250 frames 1.38 / 1.44 / 1.51 / 1.58 M frames/s against 1.37 / 1.40 / 1.43 / 1.44 M)
+    if (!form) form = (20 * G_all > (light_chroma ? 35 : 42) * ctx->n_cu || need > 16) ? 8 : 32;
     if (form == 8) {
         const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : need8;
         // (the template argument is >= nw, so "one round per step" holds for it when it holds for nw)
