@@ -655,7 +655,12 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // following only what its own stream carries, keep the early finishers busy: a part starts as soon as the part before
         // it on its stream is through (300 CIF frames: 0.94 M -> 1.04 M frames/s; 600: +1 %).
         const int NGI = (G > ctx->n_cu && !whole && !single) ? ctx->i_groups : 1;
-        const bool cap_ok = whole && ctx->chroma_cap && 8 * G <= 11 * ctx->n_cu;     // the chroma launches may take the one-workgroup-per-CU form (below)
+        // the chroma launch may take the one-workgroup-per-CU form (below): frames whose luma workgroups have at most three waves
+        // (the room left on a CU was measured for those), and as long as a CU's share of the chroma units, at 4.5 us each, stays
+        // within 0.85 of the luma step (1.67 us per wavefront step with two batches in flight) -- CIF: up to 367 frames
+        const int luma_steps = g.cols8 + 2 * (g.rows8 - 1);
+        const bool cap_ok = whole && ctx->chroma_cap && (ctx->intra_waves * 2 + 7) / 8 <= 3 &&
+                            270LL * G * cwgs <= 85LL * luma_steps * ctx->n_cu;
         if (NGI > 1) { if (int rc = group_streams(ctx, NGI)) return rc; }
         if (!single && !same && (joined || !lazy || ctx->st_ahead)) { if (int rc = fork_all(ctx)) return rc; }
         for (int k = 0; k < NGI; k++) {
@@ -676,10 +681,11 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // 300-frame batches: plain 1.44 M frames/s; k_residual8 itself with the reservation (one workgroup per CU at a time, but
         // a dispatch between any two) 1.51 M, its chroma launch 78 -> 165 us; strided with the reservation 1.57 M (0.13 ms, and
         // the step is the luma chains' again); strided without it 1.44 M, two workgroups per CU 1.49 M.  Two batches of 280 / 320 /
-        // 350 frames: 1.38 -> 1.51, 1.50 -> 1.64, 1.59 -> 1.70 M; three batches of 300 in rotation 1.39 -> 1.52 M.  With more frames
-        // per batch the one-per-CU launch no longer fits the step (two batches of 400: 1.72 -> 1.52 M, of 600: 1.98 -> 1.61 M; a
-        // batch on its own, 3390 frames: 2.26 -> 2.01 M): there, and beside the 32-lane luma form (250 frames: 1.44 -> 1.31 M),
-        // the chroma launch is the plain one.
+        // 350 frames: 1.38 -> 1.51, 1.50 -> 1.64, 1.59 -> 1.70 M; three batches of 300 in rotation 1.39 -> 1.52 M; 352x576, two
+        // batches of 300: 0.79 -> 0.85 M.  With more frames per batch the one-per-CU launch no longer fits the step (two batches of
+        // 400: 1.72 -> 1.52 M, of 600: 1.98 -> 1.61 M; a batch on its own, 3390 frames: 2.26 -> 2.01 M), and larger frames have larger
+        // luma workgroups (4CIF, two batches of 300: 0.47 -> 0.39 M; 720p -5 %, 1088p -10 %): there, and beside the 32-lane luma
+        // form (CIF, 250 frames: 1.44 -> 1.31 M), the chroma launch is the plain one (cap_ok above).
         // (A chroma stream of its own for the second chain's range does not help: the two launches then share the one
         //  workgroup slot per CU -- 0.25 ms each, 1.43 M frames/s.)
         const bool cap = cap_ok && ctx->last_form == 8;

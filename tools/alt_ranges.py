@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Resident throughput with the caller rotating over R disjoint resident ranges of n frames each (what a streaming host issues;
-bench.py's regime is R = 2): alt_ranges.py [period qp n nranges passes].  Environment (ICSP_WHOLE, ICSP_P_GROUPS, ...) is echoed."""
+bench.py's regime is R = 2): alt_ranges.py [period qp n nranges passes [width height]].  Environment (ICSP_WHOLE, ICSP_P_GROUPS, ...) is echoed."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,10 +10,17 @@ qp = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 R = int(sys.argv[4]) if len(sys.argv) > 4 else 2
 passes = int(sys.argv[5]) if len(sys.argv) > 5 else 200
+W = int(sys.argv[6]) if len(sys.argv) > 6 else 352
+H = int(sys.argv[7]) if len(sys.argv) > 7 else 288
 name = "stefanlike" if period else "foremanlike"
-enc = capi.Encoder(352, 288, qp, qp, period, max_frames=n * R)
+enc = capi.Encoder(W, H, qp, qp, period, max_frames=n * R)
 for r in range(R):
-    enc.upload(clipgen.synth_clip(name, n, first_frame=(r * n) % 600), first=r * n)
+    if (W, H) == (352, 288):
+        enc.upload(clipgen.synth_clip(name, n, first_frame=(r * n) % 600), first=r * n)
+    else:                                   # (large frames: a short clip repeated, the generator is slow)
+        base = clipgen.synth_clip(name, min(n, 10), width=W, height=H, first_frame=r)
+        for f in range(0, n, len(base)):
+            enc.upload(base[:min(len(base), n - f)], first=r * n + f)
 for k in range(100):
     enc.encode_resident((k % R) * n, n)
 enc.sync()
@@ -25,5 +32,5 @@ for rep in range(3):
     enc.sync()
     dt = (time.perf_counter() - t0) / passes
     best = max(best, n / dt)
-print(f"period={period} qp={qp} n={n} ranges={R}: {best:10.0f} fps  ({n / best * 1e3:.4f} ms/step) env={ {k: v for k, v in os.environ.items() if k.startswith(('HIP_', 'ICSP_', 'GPU_'))} }")
+print(f"{W}x{H} " * ((W, H) != (352, 288)) + f"period={period} qp={qp} n={n} ranges={R}: {best:10.0f} fps  ({n / best * 1e3:.4f} ms/step) env={ {k: v for k, v in os.environ.items() if k.startswith(('HIP_', 'ICSP_', 'GPU_'))} }")
 enc.close()
