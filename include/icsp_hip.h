@@ -37,9 +37,10 @@
  *   ICSP_SERIAL_PRIO 0|1 1 (default): the DC-chain waves of the per-frame serial kernel run at raised issue priority
  *   ICSP_SERIAL_BANDS 0|1 1 (default): frames taller than 512 lines run the bands of their DC chains as waves of one continued wavefront
  *   ICSP_WHOLE     0|1   0: never place a range whole on one stream when the caller alternates between independent ranges
- *   ICSP_CHROMA_CAP 0..120  the all-intra chroma blocks of a range placed whole (8-lane luma form, up to 1.4 frames per CU) go to one
- *                        workgroup per CU that reserves this many KB of LDS without using them, so that it stays alone on its CU beside
- *                        the other range's luma launch (default 60; 0: the plain chroma launch)
+ *   ICSP_CHROMA_CAP 0..120  the all-intra chroma blocks of a range placed whole (CIF-class frames in the 8-lane luma form, batches whose
+ *                        chroma work per CU fits the luma step: up to about 360 CIF frames) go to one workgroup per CU that reserves
+ *                        this many KB of LDS without using them, so that it stays alone on its CU beside the other range's luma
+ *                        launch (default 60; 0: always the plain chroma launch)
  *   ICSP_I_CHROMA_ON_CHAIN 0|1  1 (default): a range placed whole takes its I frames' chroma kernels to the front of its own chain
  *                        stream; 0: they stay on the second stream with the luma kernel
  *                        (icsp_encode_resident); default 1
