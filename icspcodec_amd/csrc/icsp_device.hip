@@ -1086,8 +1086,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipFuncSetAttribute((const void*)k_dec_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
-    if ((e = hipFuncSetAttribute((const void*)k_residual8, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess)
-        return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
+    // (k_residual8_strided's dynamic LDS is the reservation of encode_range's one-per-CU chroma launch: ICSP_CHROMA_CAP, up to 120 KB)
     if ((e = hipFuncSetAttribute((const void*)k_residual8_strided, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
     ctx->prio_hi = prio_hi;            // the streams of the additional GOP groups are created by the first P step that uses them
