@@ -217,6 +217,7 @@ def test_chroma_reservation_never_changes_results(cap, monkeypatch):
     """ICSP_CHROMA_CAP: the all-intra chroma launch of a range placed whole reserves LDS it does not use (default 60 KB) to stay
     at one workgroup per CU beside the other range's luma launch.  None (0) or another amount (100 KB): the same bytes."""
     monkeypatch.setenv("ICSP_CHROMA_CAP", cap)
+    monkeypatch.setenv("ICSP_WHOLE", "1")
     n = 300
     a = clipgen.synth_clip("foremanlike", n)
     b = clipgen.synth_clip("mobilelike", n, first_frame=40)
