@@ -311,10 +311,10 @@ class Encoder:
 
     def last_choice(self) -> dict:
         """What the last encode_resident chose (icsp_debug_last_choice)."""
-        v = [C.c_int(0) for _ in range(5)]
+        v = [C.c_int(0) for _ in range(6)]
         self._chk(self.lib.icsp_debug_last_choice(self.ctx, *[C.byref(x) for x in v]), "icsp_debug_last_choice")
         return {"intra_lanes_per_block": v[0].value, "intra_waves_per_workgroup": v[1].value, "intra_recon_ring": bool(v[2].value),
-                "range_whole_on_one_stream": bool(v[3].value), "gop_groups": v[4].value}
+                "range_whole_on_one_stream": bool(v[3].value), "gop_groups": v[4].value, "intra_rows_chained": v[5].value}
 
     def single_stream(self, on=True):
         """Every kernel of the context on its one stream (icsp_single_stream)."""

@@ -370,7 +370,7 @@ struct icsp_ctx {
     bool p_dirty;
     Flight flight[kMaxFlights];
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
-    int last_form, last_nw, last_ring, last_whole, last_groups;     // what the last encode chose (icsp_debug_last_choice)
+    int last_form, last_nw, last_ring, last_whole, last_groups, last_rowgroup;     // what the last encode chose (icsp_debug_last_choice)
     bool chroma_on_chain;             // ICSP_I_CHROMA_ON_CHAIN
     int chroma_cap;                   // ICSP_CHROMA_CAP: KB of LDS reserved (not used) by the all-intra chroma launch of a small range placed whole
                                       // (encode_range), on top of k_residual8's 16.9 KB.  Default 60: 77 KB per workgroup -- one per CU beside up to
@@ -382,6 +382,8 @@ struct icsp_ctx {
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
     int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
     int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
+    int force_intra_group;            // ICSP_INTRA_GROUP: 8-lane form with block rows chained in groups of 4 (4), the plain wavefront (1), or chosen (0)
+    int intra_waves_g4;               // waves of eight blocks that the widest step of the chained wavefront needs (0: geometry not supported)
     int i_groups;                     // ICSP_I_GROUPS: parts an all-intra batch of more frames than CUs is launched in (1 or 2)
     int prio_lo;
     int p_groups, prio_hi;            // GOP groups whose P-step chains run on separate streams (created on first use: a stream costs
@@ -459,6 +461,10 @@ int poison(icsp_ctx* ctx, const char* what, hipError_t e)
 // f() launches kernels on `st`; the launch status is checked here (hipLaunchKernelGGL itself returns nothing)
 template <typename F> int launch_timed(icsp_ctx* ctx, int kernel, hipStream_t st, F&& f)
 {
+    // (hipGetLastError returns -- and clears -- the last error of ANY earlier HIP call of this thread, the host's own included
+    //  (torch, RCCL, a tolerated failure of ours): drained first, so that what is read after f() is f()'s.  Our own earlier
+    //  launches were checked when they were made.)
+    (void)hipGetLastError();
     if (!ctx->profiling || !((ctx->prof_mask >> kernel) & 1u)) { f(); HIPQ(hipGetLastError()); return 0; }
     if (ctx->ev_pool.empty() && ctx->ev_pending.size() >= 8192) collect_profile(ctx);     // keeps the list bounded (this one blocks)
     EvPair e;
@@ -512,12 +518,32 @@ int intra_waves_needed(const Geo& g)
     return (widest + 1) / 2;
 }
 
+// the 8-lane kernel with block rows chained in groups of gc (k_intra_luma8<.., gc>): waves of eight slots that the widest step needs,
+// slots starting at a multiple of gc
+int intra_waves_chained(const Geo& g, int gc)
+{
+    int widest = 0;
+    const int nsteps = g.cols8 + (g.rows8 - 1) + (g.rows8 - 1) / gc;
+    for (int t = 0; t < nsteps; t++) {
+        const int tp = t - (g.cols8 - 1);
+        const int r_first = tp <= 0 ? 0 : gc * (tp / (gc + 1)) + std::min(tp % (gc + 1), gc);
+        const int r_last = std::min(g.rows8 - 1, gc * (t / (gc + 1)) + std::min(t % (gc + 1), gc - 1));
+        widest = std::max(widest, r_last - (r_first & ~(gc - 1)) + 1);
+    }
+    return (widest + 7) / 8;
+}
+
 void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma = false);
 
 // Orders `stream` after everything queued on the context's other streams (chroma stream, GOP-group streams): called by whatever
 // reads results, uploads, decodes, or encodes a range that partly overlaps one in flight.  No range is "in flight" afterwards.
 int join_all(icsp_ctx* ctx)
 {
+    // whatever was un-joined is now queued in front of `stream` only: the next encode must make the other streams follow it
+    // (fork_all), whoever the caller is (callers used to set st_ahead themselves, and one path did not)
+    bool any = ctx->s2_dirty || ctx->p_dirty;
+    for (auto& f : ctx->flight) any = any || f.used;
+    if (any) ctx->st_ahead = true;
     if (ctx->s2_dirty) {
         HIPQ(hipEventRecord(ctx->ev_join, ctx->stream2));
         HIPQ(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -830,7 +856,7 @@ int decode_range(icsp_ctx* ctx, int first, int n)
     return 0;
 }
 
-inline size_t intra8_lds_bytes(const Geo& g) { return (size_t)g.W + g.H + 8 * (size_t)(g.cols8 + 2); }     // neighbour state of one frame
+inline size_t intra8_lds_bytes(const Geo& g, int record_rows = 2) { return (size_t)g.W + g.H + 4 * (size_t)record_rows * (g.cols8 + 2); }     // neighbour state of one frame
 // ring: the reconstruction goes out through LDS in 64-byte pieces (k_intra_luma8<.., RING>): every wavefront step has to fit one
 // round of the workgroup, and the ring (4 KB per wave) is kept to workgroups of at most eight waves
 template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, bool ring, hipStream_t st)
@@ -838,11 +864,17 @@ template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const Dev
     if constexpr (NW <= 8) {
         if (ring) {
             const size_t lds = intra8_lds_bytes(g) + (size_t)ring_slots(NW) * 64 * kRingBlocks;
-            hipLaunchKernelGGL((k_intra_luma8<NW, true>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+            hipLaunchKernelGGL((k_intra_luma8<NW, true, 0>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
             return;
         }
     }
-    hipLaunchKernelGGL((k_intra_luma8<NW, false>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+    hipLaunchKernelGGL((k_intra_luma8<NW, false, 0>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+}
+// rows chained in groups of four (always with the ring; NW covers the widest step: one round)
+template <int NW> void launch_intra8_g4(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
+{
+    const size_t lds = intra8_lds_bytes(g, 4) + (size_t)ring_slots(NW) * 64 * kRingBlocks;
+    hipLaunchKernelGGL((k_intra_luma8<NW, true, 4>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
 }
 
 // G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
@@ -864,6 +896,24 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     // (beside the one-workgroup-per-CU chroma launch of a range placed whole the 8-lane form wins earlier, from 1.75 frames per CU:
     //  two batches of 220 / 230 / 240 / 250 frames 1.38 / 1.44 / 1.51 / 1.58 M frames/s against 1.37 / 1.40 / 1.43 / 1.44 M)
     if (!form) form = (20 * G_all > (light_chroma ? 35 : 42) * ctx->n_cu || need > 16) ? 8 : 32;
+    ctx->last_rowgroup = 0;
+    // rows chained in fours (k_intra_luma8<.., 4>): three quarters of the wavefront's steps for frames whose widest step fits a
+    // workgroup of at most eight waves
+    const int nw4 = ctx->intra_waves_g4;
+    bool g4 = ctx->force_intra_group == 4;
+    if (g4 && (nw4 < 1 || nw4 > 8 || !ctx->intra_ring || (ctx->force_intra_nw && ctx->force_intra_nw < nw4) || ctx->force_intra_form == 32)) g4 = false;
+    if (g4) {
+        const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : nw4;
+        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_ring = true; ctx->last_rowgroup = 4;
+        if (nw <= 1)       launch_intra8_g4<1>(g, fs, b, G, st);
+        else if (nw <= 2)  launch_intra8_g4<2>(g, fs, b, G, st);
+        else if (nw <= 3)  launch_intra8_g4<3>(g, fs, b, G, st);
+        else if (nw <= 4)  launch_intra8_g4<4>(g, fs, b, G, st);
+        else if (nw <= 5)  launch_intra8_g4<5>(g, fs, b, G, st);
+        else if (nw <= 6)  launch_intra8_g4<6>(g, fs, b, G, st);
+        else               launch_intra8_g4<8>(g, fs, b, G, st);
+        return;
+    }
     if (form == 8) {
         const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : need8;
         // (the template argument is >= nw, so "one round per step" holds for it when it holds for nw)
@@ -1047,6 +1097,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     g.mtpr = (uint32_t)(0x100000000ull / (unsigned)((g.sw + 1) / 2) + 1);
     g.fsz = (long long)g.W * g.H * 3 / 2;
     ctx->intra_waves = intra_waves_needed(g);
+    ctx->intra_waves_g4 = intra_waves_chained(g, 4);
     ctx->n_cu = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ctx->n_cu = v; }
     memset(&ctx->b, 0, sizeof(ctx->b));
@@ -1063,7 +1114,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->last_form = ctx->last_nw = ctx->last_ring = ctx->last_whole = ctx->last_groups = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
-    ctx->force_intra_nw = 0; ctx->force_intra_form = 0;
+    ctx->force_intra_nw = 0; ctx->force_intra_form = 0; ctx->force_intra_group = 0; ctx->last_rowgroup = 0;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured (300 CIF frames, period 10): 1 group 0.75 M frames/s, 2 groups 0.89 M, 3 groups -- a fourth
                                        // busy stream of the context -- 0.27 M, whatever the stream priorities and GPU_MAX_HW_QUEUES
@@ -1071,6 +1122,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) || !env_int("ICSP_I_GROUPS", 1, 2, &ctx->i_groups) ||
         !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
         (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32) ||
+        !env_int("ICSP_INTRA_GROUP", 0, 4, &ctx->force_intra_group) || (ctx->force_intra_group != 0 && ctx->force_intra_group != 1 && ctx->force_intra_group != 4) ||
         !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices) ||
         !env_int("ICSP_SERIAL_PRIO", 0, 1, &g.prio) || !env_int("ICSP_SERIAL_BANDS", 0, 1, &g.bands)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     ctx->no_fuse = no_fuse != 0;
@@ -1494,7 +1546,8 @@ int icsp_prepare(icsp_ctx_t* ctx)
     const int n = std::min(ctx->max_frames, std::max(L, 2 * L <= ctx->max_frames ? 2 * L : L));    // two GOPs when they fit: both group streams
     if (int rc = join_all(ctx)) return rc;
     // batches of 8+ GOPs run as p_groups chains, all-intra batches of more frames than CUs in i_groups parts
-    const int ngs = L > 1 ? (ctx->max_frames >= 8 * L ? ctx->p_groups : 1) : (ctx->max_frames > ctx->n_cu ? ctx->i_groups : 1);
+    // (a context in single-stream mode never uses them: icsp_enc sets that mode for one-chunk clips to save exactly this set-up)
+    const int ngs = ctx->single ? 1 : L > 1 ? (ctx->max_frames >= 8 * L ? ctx->p_groups : 1) : (ctx->max_frames > ctx->n_cu ? ctx->i_groups : 1);
     if (ngs > 1) {
         if (int rc = group_streams(ctx, ngs)) return rc;
         for (int k = 1; k < ngs; k++) HIPCHK(hipMemsetAsync(ctx->b.me_done, 0, sizeof(int), ctx->pstream[k]));    // first use of the queue
@@ -1565,9 +1618,10 @@ int icsp_single_stream(icsp_ctx_t* ctx, int on)
 // What the last icsp_encode_resident chose (bench.py puts it beside its figures, so that a line explains its own regime):
 // form of the intra luma kernel (8 / 32 lanes per block), its waves per workgroup, reconstruction through the LDS ring or not, whether the range went
 // whole onto one chain stream, GOP groups.  Any pointer may be null.
-int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups)
+int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups, int* intra_row_group)
 {
     ENTER(ctx);
+    if (intra_row_group) *intra_row_group = ctx->last_rowgroup;
     if (intra_form) *intra_form = ctx->last_form;
     if (intra_waves) *intra_waves = ctx->last_nw;
     if (intra_recon_ring) *intra_recon_ring = ctx->last_ring;

@@ -32,6 +32,8 @@
  *   ICSP_INTRA_FORM 8|32 lanes per 8x8 block in the intra luma kernel: 32 = latency form (two blocks per wave), 8 = throughput
  *                        form (eight blocks per wave); default: 8 when there are more than 2.1 frames per CU or the frame is
  *                        wider than one round of the 32-lane form, else 32
+ *   ICSP_INTRA_GROUP 0|1|4  8-lane intra kernel: 4 = block rows run one wavefront step apart in groups of four (87 steps per CIF frame
+ *                        instead of 114; frames whose widest step fits eight waves), 1 = two steps apart throughout, 0 (default) = chosen
  *   ICSP_INTRA_RING 0|1  8-lane intra kernel: reconstruction written in 32-byte runs through a ring in LDS (default 1) or as 8-byte
  *                        block rows straight from the lanes (0)
  *   ICSP_SERIAL_PRIO 0|1 1 (default): the DC-chain waves of the per-frame serial kernel run at raised issue priority
@@ -132,9 +134,9 @@ int icsp_download_debug(icsp_ctx_t* ctx, int first_frame, int n, int8_t* mv, uin
 int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
 /* What the last icsp_encode_resident chose: intra luma kernel form (8 or 32 lanes per block), its waves per workgroup, whether the
- * 8-lane form wrote the reconstruction through its LDS ring (0/1), range placed whole on one chain stream (0/1), GOP groups.
- * Any pointer may be NULL.  For reports. */
-int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups);
+ * 8-lane form wrote the reconstruction through its LDS ring (0/1), range placed whole on one chain stream (0/1), GOP groups, block
+ * rows of the 8-lane form's wavefront chained in groups of (4) or not (0).  Any pointer may be NULL.  For reports. */
+int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups, int* intra_row_group);
 /* Test hook, needs no device: a context shell in the state a failed launch-path call leaves behind (poisoned).  Every entry
  * point answers ICSP_ERR_HIP on it without touching the runtime; release it with icsp_destroy. */
 int icsp_debug_poisoned_context(icsp_ctx_t** out);

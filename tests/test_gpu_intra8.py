@@ -53,6 +53,81 @@ def test_forced_8_lane_form_matches_oracle(form8, name, n, qdc, qac, period, w, 
     assert np.array_equal(mode[0], dbg["mode"])
 
 
+@pytest.fixture
+def rows4(monkeypatch):
+    monkeypatch.setenv("ICSP_INTRA_GROUP", "4")
+
+
+@pytest.mark.parametrize("name,n,qdc,qac,period,w,h", [
+    ("foremanlike", 4, 16, 16, 0, 352, 288), ("mobilelike", 3, 1, 1, 0, 352, 288), ("stefanlike", 6, 8, 8, 3, 352, 288),
+    ("mobilelike", 3, 16, 1, 3, 352, 288), ("staticlike", 4, 1, 1, 4, 352, 288), ("tablelike", 3, 8, 8, 0, 64, 48),
+    ("newslike", 2, 16, 16, 0, 32, 16), ("stefanlike", 3, 8, 8, 3, 416, 240), ("mobilelike", 2, 3, 255, 0, 720, 480),
+    ("mobilelike", 2, 16, 16, 2, 32, 2304), ("tablelike", 2, 8, 8, 0, 4096, 32), ("stefanlike", 2, 1, 1, 0, 48, 1600),
+    ("mobilelike", 2, 2, 5, 0, 176, 144), ("foremanlike", 2, 31, 2, 0, 352, 80), ("mobilelike", 2, 64, 64, 0, 1024, 512),
+])
+def test_rows_chained_in_fours_matches_oracle(rows4, name, n, qdc, qac, period, w, h):
+    """k_intra_luma8<.., 4>: block rows one wavefront step apart in groups of four, the DC predictors that need the upper-right
+    neighbour of the same step resolved through the lanes (DPCM_DC_block's median, ENC:3652-3818).  Every output and the forward
+    coefficients (0 ulp) against the oracle; the geometries include one-wave frames, eight-wave frames and tall narrow ones."""
+    clip = clipgen.synth_clip(name, n, width=w, height=h)
+    enc = capi.Encoder(w, h, qdc, qac, period, max_frames=n)
+    enc.keep_coef(True)
+    got = enc.encode(clip)
+    ch = enc.last_choice()
+    coef = enc.download_coef(0, 1)
+    mv, mode = enc.download_debug(0, n)
+    enc.close()
+    assert (ch["intra_lanes_per_block"], ch["intra_rows_chained"], ch["intra_recon_ring"]) == (8, 4, True)
+    want = po.encode_sequence(clip, w, h, qdc, qac, period, nthreads=NT)
+    _cmp(got, want, f"{name} {w}x{h} n={n} q={qdc}/{qac} p={period}: ")
+    dbg = po.intra_frame(clip[0], w, h, qdc, qac, want_dbg=True)
+    assert np.array_equal(coef[0].view(np.int64), dbg["coef"].view(np.int64))
+    assert np.array_equal(mode[0], dbg["mode"])
+
+
+@pytest.mark.parametrize("w,h", [(704, 576), (1920, 1088)])
+def test_rows_chained_falls_back_where_a_step_does_not_fit_eight_waves(rows4, w, h):
+    clip = clipgen.synth_clip("mobilelike", 2, width=w, height=h)
+    enc = capi.Encoder(w, h, 8, 8, 0, max_frames=2)
+    got = enc.encode(clip)
+    ch = enc.last_choice()
+    enc.close()
+    assert ch["intra_rows_chained"] == 0
+    _cmp(got, po.encode_sequence(clip, w, h, 8, 8, 0, nthreads=NT), f"{w}x{h}: ")
+
+
+@pytest.mark.parametrize("nw", ["6", "8"])
+def test_rows_chained_with_idle_waves(rows4, nw, monkeypatch):
+    monkeypatch.setenv("ICSP_INTRA_NW", nw)
+    clip = clipgen.synth_clip("foremanlike", 2)
+    enc = capi.Encoder(352, 288, 16, 16, 0, max_frames=2)
+    got = enc.encode(clip)
+    ch = enc.last_choice()
+    enc.close()
+    assert ch["intra_rows_chained"] == 4 and ch["intra_waves_per_workgroup"] == int(nw)
+    _cmp(got, po.encode_sequence(clip, 352, 288, 16, 16, 0), f"NW={nw}: ")
+
+
+def test_rows_chained_reference_clip(rows4):
+    """300 frames of the clip the reference CLI was run on: its reconstruction and .bin hashes."""
+    import hashlib
+    import json
+    clip = clipgen.synth_clip("foremanlike", 300)
+    enc = capi.Encoder(352, 288, 16, 16, 0, max_frames=300)
+    enc.upload(clip)
+    for _ in range(3):
+        enc.encode_resident(0, 300)
+    rec = enc.download(0, 300, what=("recon",))["recon"]
+    bs = enc.pack_bitstream(0, 300)
+    ch = enc.last_choice()
+    enc.close()
+    assert ch["intra_rows_chained"] == 4
+    ref = next(s for s in json.load(open(os.path.join(os.path.dirname(__file__), "golden", "streams.json")))
+               if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", 300, 16, 0) and "bin_sha256" in s)
+    assert hashlib.sha256(rec.tobytes()).hexdigest() == ref["recon_sha256"]
+    assert hashlib.sha256(bs).hexdigest() == ref["bin_sha256"]
+
+
 @pytest.mark.parametrize("ring", ["0", "1"])
 @pytest.mark.parametrize("w,h,n,period", [(352, 288, 3, 0), (48, 64, 4, 2), (80, 32, 3, 0), (112, 48, 3, 3), (144, 176, 2, 0), (704, 576, 2, 0)])
 def test_8_lane_form_variants(form8, ring, w, h, n, period):
@@ -146,7 +221,7 @@ def test_all_intra_batch_in_two_parts_back_to_back(parts):
 
 
 @pytest.mark.parametrize("var,val", [("ICSP_I_GROUPS", "3"), ("ICSP_P_GROUPS", "0"), ("ICSP_NO_FUSE", "yes"), ("ICSP_INTRA_FORM", "16"),
-                                     ("ICSP_INTRA_NW", "17"), ("ICSP_XCD_SLICES", "-1"), ("ICSP_I_GROUPS", ""), ("ICSP_INTRA_RING", "2"), ("ICSP_CHROMA_CAP", "121")])
+                                     ("ICSP_INTRA_NW", "17"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_XCD_SLICES", "-1"), ("ICSP_I_GROUPS", ""), ("ICSP_INTRA_RING", "2"), ("ICSP_CHROMA_CAP", "121")])
 def test_override_outside_its_range_fails_the_create(var, val):
     """include/icsp_hip.h: a tuning override that is not a whole number in its range makes icsp_create fail."""
     os.environ[var] = val
