@@ -61,8 +61,7 @@ BYTES_P_FRAME_READ = 3 * P
 # k_residual reads cur 1.5P + prediction 1.5P, writes recon 1.5P + levels 3P + 8 B/MB
 BYTES_P_KERNEL = {"k_me": 3 * P + 64 * NMB, "k_frame_serial": 84 * NMB, "k_residual": 3 * P + P * 3 // 2 + 3 * P + 8 * NMB}
 
-CLIPS12 = ["akiyolike", "childrenlike", "coastguardlike", "containerlike", "footballlike", "foremanlike", "hallmonitorlike",
-           "mobilelike", "motherdaughterlike", "newslike", "stefanlike", "tablelike"]
+from icspcodec_amd.workloads import CLIPS12  # noqa: E402,F401
 
 
 # ------------------------------------------------------------------------------------------------ launcher
@@ -86,7 +85,7 @@ def cpu_baseline():
     back to the oracle's GOP thread pool ("port") when the reference binary did not travel.  Rank 0 at N=1 only."""
     from icspcodec_amd import clipgen
     from oracle import pyoracle as po
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) or 1
     clip = clipgen.synth_clip("foremanlike", NFRAMES)
     port_threads = min(cores, 64)
     t0 = time.perf_counter()
@@ -127,6 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=5, help="how often the K-step timed region is repeated (value = the median)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--legs", default="ippp,config4,config5,e2e", help="secondary legs to run (comma list; '' = none)")
     a = ap.parse_args()
@@ -151,9 +151,28 @@ def main():
     # this rank's host thread (and the threads it starts from here on) onto the NUMA node its GPU hangs off: a no-op on one node
     _lib = capi.load()
     import ctypes as _C
+    import contextlib
     _bound = _C.c_int(0)
     _node = _lib.icsp_device_numa_node(local)
+    _aff_all = os.sched_getaffinity(0)                 # before the binding: what the CPU-side legs (baseline, oracle checks) may use
     _lib.icsp_bind_thread_to_node(_node, _C.byref(_bound))
+    _aff_bound = os.sched_getaffinity(0)
+
+    @contextlib.contextmanager
+    def all_cores():
+        """The CPU baseline and the oracle's thread pools size themselves by the host's cores; run them on every core this
+        process was given, not on the GPU's NUMA node alone, and go back to the node afterwards."""
+        try:
+            os.sched_setaffinity(0, _aff_all)
+        except OSError:
+            pass
+        try:
+            yield
+        finally:
+            try:
+                os.sched_setaffinity(0, _aff_bound)
+            except OSError:
+                pass
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # nccl == RCCL on ROCm
@@ -174,13 +193,42 @@ def main():
         return float(t.item())
     ranks_seen = int(reduce(1.0, dist.ReduceOp.SUM)) if world > 1 else 1
 
-    def timed(enc, n, steps, warmup, dominant):
-        """K timed steps alternating between the resident batches at slots [0, n) and [n, 2n) (HIP events only around the
-        dominant kernel, none if it is None), then four untimed passes with events on every kernel."""
+    # counters of the round's rocprofv3 --pmc passes over the same workloads (tools/profile_round.sh -> profiles/traffic.json)
+    try:
+        _tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:
+        _tj = {}
+    ISSUE_PEAK = 256 * 4 * 2.4e9 / 4                     # wave-instructions/s: 256 CUs x 4 SIMDs, one per 4 cycles at 2.4 GHz
+
+    def leg_issue(leg, sec_per_pass, ranks=1):
+        """What binds a loaded leg: the vector instructions of ONE pass of the leg (SQ_INSTS_VALU summed over the pass's
+        launches, rocprofv3 --pmc on tools/leg_workload.py <leg>, whole batch on one GPU) over this run's time per pass, as a share
+        of the chip's vector issue slots; the fp64 share; how much of their lifetime the waves spent waiting.  None without
+        a counter file of the leg.  (N ranks: each holds 1/N of the batch.)"""
+        e = (_tj.get("legs") or {}).get(leg)
+        if not e or not sec_per_pass:
+            return None
+        vi, f64 = e.get("valu_insts_per_pass", 0), e.get("fp64_valu_insts_per_pass", 0)
+        out = {"valu_issue_frac": round(vi / ranks / sec_per_pass / ISSUE_PEAK, 4),
+               "fp64_valu_frac": round(f64 / ranks * 64 / sec_per_pass / 1e9 / FP64_VALU_PEAK_GOPS, 4),
+               "waiting_share_of_wave_cycles": e.get("waiting_share_of_wave_cycles"),
+               "valu_insts_per_pass": int(vi), "hbm_bytes_per_pass": e.get("hbm_bytes_per_pass"),
+               "traffic_over_algorithmic": e.get("traffic_over_algorithmic"),
+               "by_kernel": e.get("by_kernel"),
+               "source": e.get("source"),
+               "is": "vector wave-instructions of one pass / time per pass of THIS run / (1024 SIMDs x 2.4 GHz / 4): the share of "
+                     "the chip's vector issue slots the leg fills -- the ceiling that binds these kernels (DESIGN.md section 5)"}
+        return out
+
+    def timed(enc, n, steps, warmup, dominant, alternate=True):
+        """The K-step timed region, `a.repeats` times over (each bracketed by barrier + synchronize; the list of their
+        durations comes back, max over ranks each): steps alternating between the resident batches at slots [0, n) and
+        [n, 2n) -- or, alternate=False, the batch at [0, n) again and again -- with HIP events only around the dominant kernel
+        (none if it is None); then four untimed passes with events on every kernel."""
         step_no = [0]
 
         def one_step():
-            enc.encode_resident((step_no[0] & 1) * n, n)
+            enc.encode_resident((step_no[0] & 1) * n if alternate else 0, n)
             step_no[0] += 1
         for _ in range(SETTLE_PASSES):              # fixed settle (clock ramp, instruction and TLB warm-up): independent of W
             one_step()
@@ -193,20 +241,22 @@ def main():
             enc.profile(True, only=[dominant])          # creates the events, clears the sums
             flag = 1 << (capi.KERNELS.index(dominant) + 1)
             enc.lib.icsp_profile_enable(enc.ctx, 0)
-        barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            # the two event records around the dominant kernel cost the stream about 15 us a step (5 % of this one): every
-            # EVENT_EVERY-th step carries them, the average launch duration is over those
-            ev = flag and i % EVENT_EVERY == 0
-            if ev:
-                enc.lib.icsp_profile_enable(enc.ctx, flag)
-            one_step()
-            if ev:
-                enc.lib.icsp_profile_enable(enc.ctx, 0)
-        enc.sync()
-        barrier()
-        dt = time.perf_counter() - t0
+        dts = []
+        for _rep in range(max(1, a.repeats)):
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                # the two event records around the dominant kernel cost the stream about 15 us a step (5 % of this one): every
+                # EVENT_EVERY-th step carries them, the average launch duration is over those
+                ev = flag and i % EVENT_EVERY == 0
+                if ev:
+                    enc.lib.icsp_profile_enable(enc.ctx, flag)
+                one_step()
+                if ev:
+                    enc.lib.icsp_profile_enable(enc.ctx, 0)
+            enc.sync()
+            barrier()
+            dts.append(reduce(time.perf_counter() - t0, dist.ReduceOp.MAX))
         dom_ms, dom_n = enc.profile_get()[dominant] if dominant else (0.0, 0)
         enc.profile(True)
         for _ in range(4):
@@ -214,7 +264,16 @@ def main():
         enc.sync()
         prof = {k: (v[0] / 4.0, v[1] // 4) for k, v in enc.profile_get().items()}      # (ms per pass, launches per pass)
         enc.profile(False)
-        return reduce(dt, dist.ReduceOp.MAX), prof, (dom_ms, dom_n)
+        return dts, prof, (dom_ms, dom_n)
+
+    def med(xs):
+        return sorted(xs)[len(xs) // 2]
+
+    def spread(dts, frames_per_region):
+        """the repeats of a timed region as rates: median, fastest, slowest"""
+        r = sorted(frames_per_region / d for d in dts)
+        return {"repeats": len(r), "median": round(r[len(r) // 2], 1), "min": round(r[0], 1), "max": round(r[-1], 1),
+                "spread_pct": round(100.0 * (r[-1] - r[0]) / r[len(r) // 2], 2)}
 
     def timed_passes(enc, n, passes):
         """Big batches: warm passes for at least 40 ms (two at the least: the GPU clock ramps), then `passes` timed ones
@@ -254,8 +313,15 @@ def main():
     enc = capi.Encoder(W, H, 16, 16, 0, device=local, max_frames=2 * NFRAMES)
     enc.upload(clip, first=0)
     enc.upload(clip_b, first=NFRAMES)
-    dt, prof, (ms_ai, n_ai) = timed(enc, NFRAMES, a.steps, a.warmup, "k_intra_luma")
+    dts_ai, prof, (ms_ai, n_ai) = timed(enc, NFRAMES, a.steps, a.warmup, "k_intra_luma")
+    dt = med(dts_ai)
     choice_ai = enc.last_choice()
+    # the regime of rounds 1 and 2, kept beside `value` so that round-over-round figures stay like for like: ONE
+    # resident 300-frame batch encoded again and again (the library then runs it in two parts on two streams)
+    dts_same, _, (ms_same, n_same) = timed(enc, NFRAMES, a.steps, a.warmup, "k_intra_luma", alternate=False)
+    choice_same = enc.last_choice()
+    enc.encode_resident(NFRAMES, NFRAMES)              # (both batches' results are checked below)
+    enc.sync()
     recon = enc.download(0, NFRAMES, what=("recon",))["recon"]
     recon_b = enc.download(NFRAMES, NFRAMES, what=("recon",))["recon"]
     iso_ai = isolated_pass_ms(enc, NFRAMES)
@@ -266,7 +332,8 @@ def main():
         ref = next(s for s in golden if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", 300, 16, 0) and "bin_sha256" in s)
         parity["configs1_recon_sha_equals_reference"] = hashlib.sha256(recon.tobytes()).hexdigest() == ref["recon_sha256"]
         parity["configs1_bin_sha_equals_reference"] = hashlib.sha256(enc.pack_bitstream(0, NFRAMES)).hexdigest() == ref["bin_sha256"]
-        parity["configs1_batch_b_recon_equals_oracle"] = bool(np.array_equal(recon_b, po.encode_sequence(clip_b, W, H, 16, 16, 1, nthreads=ncore)["recon"]))
+        with all_cores():
+            parity["configs1_batch_b_recon_equals_oracle"] = bool(np.array_equal(recon_b, po.encode_sequence(clip_b, W, H, 16, 16, 1, nthreads=ncore)["recon"]))
     del recon_b
     # PCIe-inclusive (host buffers in, host results out) — reported, never `value`
     t0 = time.perf_counter()
@@ -307,7 +374,8 @@ def main():
     # little about the chip.  Chip-level figure: the kernel's algorithmic bytes of a step over the step's share of
     # the timed region -- in steady state the span of a step's launches -- i.e. bytes per step / ms_per_step.  The per-launch
     # figure of the contract (bytes of one launch / its average duration under HIP events) is kept beside it.
-    lps = max(1, round(n_ai / max(1, (a.steps + EVENT_EVERY - 1) // EVENT_EVERY)))
+    n_ev_steps = max(1, a.repeats) * ((a.steps + EVENT_EVERY - 1) // EVENT_EVERY)     # timed steps that carried events
+    lps = max(1, round(n_ai / max(1, n_ev_steps)))
     step_ms = dt / a.steps * 1e3
     achieved = BYTES_INTRA_LUMA_KERNEL * NFRAMES / (step_ms * 1e-3) / 1e9
     single_launch = BYTES_INTRA_LUMA_KERNEL * NFRAMES / lps / (kern_ms * 1e-3) / 1e9 if n_ai else 0.0
@@ -321,8 +389,12 @@ def main():
         enc2.upload(clip2, first=0)
         enc2.upload(clip2_b, first=NFRAMES)
         steps2 = max(2, a.steps)
-        dt2, prof2, _ = timed(enc2, NFRAMES, steps2, a.warmup, None)      # no events inside this timed region
+        dts_ip, prof2, _ = timed(enc2, NFRAMES, steps2, a.warmup, None)      # no events inside this timed region
+        dt2 = med(dts_ip)
         choice_ip = enc2.last_choice()
+        dts_ip_same, _, _ = timed(enc2, NFRAMES, steps2, a.warmup, None, alternate=False)
+        enc2.encode_resident(NFRAMES, NFRAMES)
+        enc2.sync()
         recon2 = enc2.download(0, NFRAMES, what=("recon",))["recon"]
         recon2_b = enc2.download(NFRAMES, NFRAMES, what=("recon",))["recon"]
         iso_ip = isolated_pass_ms(enc2, NFRAMES)
@@ -330,7 +402,8 @@ def main():
         if rank == 0:
             ref = next(s for s in golden if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("stefanlike", 300, 8, 10))
             parity["configs2_recon_sha_equals_reference"] = hashlib.sha256(recon2.tobytes()).hexdigest() == ref["recon_sha256"]
-            parity["configs2_batch_b_recon_equals_oracle"] = bool(np.array_equal(recon2_b, po.encode_sequence(clip2_b, W, H, 8, 8, 10, nthreads=ncore)["recon"]))
+            with all_cores():
+                parity["configs2_batch_b_recon_equals_oracle"] = bool(np.array_equal(recon2_b, po.encode_sequence(clip2_b, W, H, 8, 8, 10, nthreads=ncore)["recon"]))
         del recon2_b
         dec_ip_fps = decode_fps(enc2)
         enc2.close()
@@ -361,6 +434,9 @@ def main():
         ippp = {"workload": "stefanlike_cif 300f, --intraPeriod 10, QP=8 (BASELINE configs[2]), per GPU; steps alternate between two "
                             "disjoint resident 300-frame batches (frames 0-299 and 300-599 of the sequence)", "value": round(fps2, 1),
                 "unit": "frames/s", "ms_per_step": round(dt2 / steps2 * 1e3, 4), "psnr_y_db": round(psnr_ip, 4),
+                "value_is": "median of the repeats of the K-step region", "repeats": spread(dts_ip, world * NFRAMES * steps2),
+                "value_same_range": round(world * NFRAMES * steps2 / med(dts_ip_same), 1),
+                "same_range_repeats": spread(dts_ip_same, world * NFRAMES * steps2),
                 "isolated_pass": {"ms": round(iso_ip, 4), "fps": round(NFRAMES / iso_ip * 1e3, 1),
                                   "note": "one pass, host waits before and after: nothing runs beside it"},
                 "regime": dict(choice_ip, gops_per_rank_per_step=NFRAMES // 10, frames_in_flight_per_cu=round(2 * NFRAMES / 256, 2)),
@@ -374,21 +450,9 @@ def main():
     # ---- configs[3]: the twelve clips as ONE batch of 339 closed GOPs, sharded over the ranks (strong scaling)
     config4 = None
     if "config4" in legs:
-        from oracle import pyoracle as po
-        units = []                                                     # (clip, first frame of the GOP, frames)
-        for name in CLIPS12:
-            n = clipgen.CLIP_CLASSES[name]["nframes"]
-            units += [(name, f, min(10, n - f)) for f in range(0, n, 10)]
-        per = len(units) // world
-        lo = rank * per + min(rank, len(units) % world)
-        mine = units[lo: lo + per + (1 if rank < len(units) % world else 0)]
-        cache, parts = {}, []
-        for name, f, cnt in mine:
-            if name not in cache:
-                cache = {name: clipgen.synth_clip(name)}                # whole clip once, GOPs are slices of it
-            parts.append(cache[name][f: f + cnt])
-        batch = np.concatenate(parts)
-        nloc, ntot = batch.shape[0], sum(u[2] for u in units)
+        from icspcodec_amd import workloads
+        batch, mine, ntot = workloads.clips12_shard(rank, world)
+        nloc = batch.shape[0]
         enc4 = capi.Encoder(W, H, 16, 16, 10, device=local, max_frames=nloc)
         enc4.upload(batch)
         sec = timed_passes(enc4, nloc, 5)
@@ -404,8 +468,9 @@ def main():
                 ok4 &= hashlib.sha256(rec4[pos: pos + n].tobytes()).hexdigest() == ref["recon_sha256"]
                 pos += n
         else:                 # a rank holds runs of GOPs: its first and last GOP against the oracle
-            for sl in (slice(0, mine[0][2]), slice(nloc - mine[-1][2], nloc)):
-                ok4 &= np.array_equal(rec4[sl], po.encode_sequence(batch[sl], W, H, 16, 16, 10)["recon"])
+            with all_cores():
+                for sl in (slice(0, mine[0][2]), slice(nloc - mine[-1][2], nloc)):
+                    ok4 &= np.array_equal(rec4[sl], po.encode_sequence(batch[sl], W, H, 16, 16, 10)["recon"])
         ok4 = reduce(1.0 if ok4 else 0.0, dist.ReduceOp.MIN) == 1.0 if world > 1 else ok4
         enc4.close()
         # the same frames all-intra: every CU busy (the throughput regime of the intra kernels)
@@ -426,34 +491,22 @@ def main():
                                        "towards the latency regime of configs[2] (30 GOPs); a rank's own isolated pass is listed so that "
                                        "an N-rank line explains its efficiency"),
                    "read_roofline_frac": round(ntot / sec * (BYTES_I_FRAME_READ + 9 * BYTES_P_FRAME_READ) / 10.0 / 1e9 / HBM_PEAK_GBS / world, 5),
+                   "issue": leg_issue("config4", sec, world),
                    "all_intra_loaded": {"value": round(ntot / sec_i, 1), "unit": "frames/s", "ms_per_pass": round(sec_i * 1e3, 3),
+                                        "issue": leg_issue("config4_allintra", sec_i, world),
                                         "regime": dict(choice4i, frames_per_rank=nloc, frames_per_cu=round(nloc / 256, 2)),
                                         "read_roofline_frac": round(ntot / sec_i * BYTES_I_FRAME_READ / 1e9 / HBM_PEAK_GBS / world, 5),
                                         "rw_roofline_frac": round(ntot / sec_i * BYTES_I_FRAME_TOTAL / 1e9 / HBM_PEAK_GBS / world, 5)}}
-        del batch, rec4, parts, cache
+        del batch, rec4
 
     # ---- configs[4]: 1920x1088, --intraPeriod 30, 3000 frames = 100 GOPs sharded over the ranks (strong scaling)
     config5 = None
     if "config5" in legs:
-        from oracle import pyoracle as po
-        w5, h5, L5, ngop5 = 1920, 1088, 30, 100
-        fsz5 = w5 * h5 * 3 // 2
-        per = ngop5 // world
-        g_lo = rank * per + min(rank, ngop5 % world)
-        g_n = per + (1 if rank < ngop5 % world else 0)
+        from icspcodec_amd import workloads
+        w5, h5, L5, ngop5 = workloads.HD_W, workloads.HD_H, workloads.HD_PERIOD, workloads.HD_GOPS
+        srcs = workloads.HD_SRCS
         # "CIF-tiled macroblock grid": a 1088p frame is the CIF frame tiled; GOP g shows clip (g mod 4), so four distinct GOPs
-        srcs = ["foremanlike", "stefanlike", "mobilelike", "akiyolike"]
-
-        def hd_gop(name):
-            c = clipgen.synth_clip(name, L5)
-            out = np.empty((L5, fsz5), np.uint8)
-            for i in range(L5):
-                y = c[i, :P].reshape(H, W); cb = c[i, P: P + P // 4].reshape(H // 2, W // 2); cr = c[i, P + P // 4:].reshape(H // 2, W // 2)
-                out[i, : w5 * h5] = np.tile(y, (4, 6))[:h5, :w5].ravel()
-                out[i, w5 * h5: w5 * h5 * 5 // 4] = np.tile(cb, (4, 6))[: h5 // 2, : w5 // 2].ravel()
-                out[i, w5 * h5 * 5 // 4:] = np.tile(cr, (4, 6))[: h5 // 2, : w5 // 2].ravel()
-            return out
-        gops = {nm: hd_gop(nm) for nm in {srcs[(g_lo + g) % 4] for g in range(g_n)}}
+        g_lo, g_n, gops = workloads.hd_shard(rank, world)
         enc5 = capi.Encoder(w5, h5, 16, 16, L5, device=local, max_frames=g_n * L5)
         for g in range(g_n):
             enc5.upload(gops[srcs[(g_lo + g) % 4]], first=g * L5)
@@ -465,7 +518,8 @@ def main():
         for g in range(g_n):
             first_of.setdefault((g_lo + g) % 4, g)
         check = sorted(first_of.items())[: (4 if world == 1 else 1)]
-        want = po.encode_sequence(np.concatenate([gops[srcs[k]] for k, _ in check]), w5, h5, 16, 16, L5, nthreads=len(check))["recon"]
+        with all_cores():
+            want = po.encode_sequence(np.concatenate([gops[srcs[k]] for k, _ in check]), w5, h5, 16, 16, L5, nthreads=len(check))["recon"]
         ok5 = True
         for j, (k, g) in enumerate(check):
             ok5 &= np.array_equal(enc5.download(g * L5, L5, what=("recon",))["recon"], want[j * L5: (j + 1) * L5])
@@ -479,6 +533,7 @@ def main():
                    "cif_equivalent_fps": round(n5 / sec5 * (w5 * h5) / P, 1), "recon_equals_oracle": bool(ok5),
                    "regime": dict(choice5, gops_per_rank=g_n, frames_per_rank=g_n * L5, macroblocks_per_p_step_per_cu=round(g_n * 8160 / 256, 1),
                                   isolated_pass_ms_this_rank=round(iso5, 2), isolated_pass_fps_this_rank=round(g_n * L5 / iso5 * 1e3, 1)),
+                   "issue": leg_issue("config5", sec5, world),
                    "read_roofline_frac": round(n5 / sec5 * rd5 / 1e9 / HBM_PEAK_GBS / world, 5)}
         del gops
 
@@ -545,40 +600,49 @@ def main():
                 if os.path.exists(f):
                     os.remove(f)
 
-    cpu = None if (a.no_cpu or world > 1 or rank != 0) else cpu_baseline()      # CPU baseline: rank 0 at N=1 only
+    cpu = None
+    if not (a.no_cpu or world > 1 or rank != 0):       # CPU baseline: rank 0 at N=1 only, on every core the process was given
+        with all_cores():
+            cpu = cpu_baseline()
+            cpu["host_cores_available"] = len(_aff_all)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
         return
 
-    traffic, pmc = None, None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj.get("k_intra_luma_bytes_per_launch")
-            pmc = tj.get("k_intra_luma_sq")
-        except Exception:
-            traffic = None
-    roof = {"bound": "hbm", "kernel": "k_intra_luma", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "traffic_is": "HBM-side bytes of one step's launch(es) of the kernel (rocprofv3 TCC counters of a 300-frame launch of the same kernel variant, "
+    traffic, pmc = _tj.get("k_intra_luma_bytes_per_launch"), _tj.get("k_intra_luma_sq")
+    overlap = None
+    try:
+        ov = json.load(open(os.path.join(ROOT, "profiles", "r04_overlap.json")))
+        overlap = {k: ov[k] for k in ("launches_in_flight_median", "launch_duration_ms_median", "start_to_start_ms_median",
+                                      "chip_level_GBps_from_trace", "source") if k in ov}
+    except Exception:
+        pass
+    chip = achieved                                    # kernel's algorithmic bytes of a step / ms_per_step
+    roof = {"bound": "hbm", "kernel": "k_intra_luma", "achieved": round(single_launch, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(single_launch / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "achieved_is": "the contract's per-launch figure: algorithmic_bytes_per_launch / avg_launch_ms, the launch's own duration "
+                           "under HIP events on the stream it runs on (every 4th step of the timed region).  Two such launches are in "
+                           "flight at any time (two batches on two streams, profiles/r04_overlap.json), each on about half the "
+                           "chip's issue slots: see chip_level",
+            "traffic_is": "HBM-side bytes of one launch of the kernel (rocprofv3 TCC counters of a 300-frame launch of the same kernel variant, "
                           "tools/pmc_workload.py -> profiles/traffic.json)",
             "traffic_over_algorithmic": round(traffic / (BYTES_INTRA_LUMA_KERNEL * NFRAMES), 3) if traffic else None,
             "launches_per_step": lps,
-            "achieved_is": "chip level: the kernel's algorithmic bytes of one step (launches_per_step x algorithmic_bytes_per_launch) / "
-                           "ms_per_step; launches of one step and of consecutive steps (independent batches) run side by side, so a "
-                           "launch's own duration overstates and understates nothing here",
-            "single_launch": {"achieved": round(single_launch, 2), "frac": round(single_launch / HBM_PEAK_GBS, 5),
-                              "is": "algorithmic_bytes_per_launch / avg_launch_ms (HIP events around the launch; other launches share the chip with it)"},
             "algorithmic_bytes_per_launch": BYTES_INTRA_LUMA_KERNEL * NFRAMES // lps, "avg_launch_ms": round(kern_ms, 4),
-            "avg_launch_over": f"HIP events around the launches of every {EVENT_EVERY}th step of the timed region ({n_ai} launches)",
+            "avg_launch_over": f"HIP events around the launches of every {EVENT_EVERY}th step of the timed regions ({n_ai} launches)",
+            "chip_level": {"achieved": round(chip, 2), "frac": round(chip / HBM_PEAK_GBS, 5),
+                           "is": "the kernel's algorithmic bytes of one step / ms_per_step (median region): what the chip as a whole "
+                                 "moves for this kernel while launches of consecutive steps run side by side; avg_launch_ms > "
+                                 "ms_per_step is that overlap", "kernel_trace": overlap},
             "whole_frame_read_frac": round(fps / world * BYTES_I_FRAME_READ / 1e9 / HBM_PEAK_GBS, 5),
             "whole_frame_rw_frac": round(fps / world * BYTES_I_FRAME_TOTAL / 1e9 / HBM_PEAK_GBS, 5),
-            "limiter": "the contract's roofline is HBM; what actually limits this kernel is the 114-step dependency chain of a CIF "
-                       "frame: its waves wait (LDS round trips, step barrier: waiting_share_of_wave_cycles) more than they issue, with "
-                       "2.3 frames per CU in flight (DESIGN.md §5); see fp64_valu_frac / valu_issue_frac"}
+            "limiter": "the contract's roofline is HBM; what binds this kernel is vector issue on a dependency chain: a CIF frame is 114 "
+                       "wavefront steps, a step is as long as its busiest SIMD needs to issue the block tasks that landed on it (one "
+                       "task: about 700 vector + 250 scalar instructions; one wave issues an instruction every 4 cycles), and with 2.3 "
+                       "frames per CU in flight the chip's issue slots are 37 % full (valu_issue_frac; 55-70 % on a loaded chip: "
+                       "config4.all_intra_loaded.issue) -- DESIGN.md section 5"}
     if pmc and kern_ms > 0:
         # chip level, like `achieved`: the instructions of one step's launches (counters of one 300-frame launch of the same kernel
         # x launches per step) over the step's share of the timed region
@@ -602,6 +666,15 @@ def main():
         "metric": "CIF encode fps, resident encode loop (all-intra QP=16; IPPP and the 8-GPU workloads alongside)", "value": round(fps, 1),
         "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": round(dt / a.steps * 1e3, 4),
+        "value_is": "median of the repeats of the K-step timed region (each bracketed by barrier + synchronize)",
+        "repeats": spread(dts_ai, world * NFRAMES * a.steps),
+        "value_same_range": round(world * NFRAMES * a.steps / med(dts_same), 1),
+        "same_range": {"is": "the regime of rounds 1-2, for like-for-like comparison across rounds: ONE resident 300-frame batch "
+                             "encoded again and again (two parts on two streams), K steps, same repeats",
+                       "ms_per_step": round(med(dts_same) / a.steps * 1e3, 4), "repeats": spread(dts_same, world * NFRAMES * a.steps),
+                       "regime": choice_same,
+                       "roofline_per_launch": {"avg_launch_ms": round(ms_same / max(n_same, 1), 4), "launches": n_same,
+                                               "achieved": round(BYTES_INTRA_LUMA_KERNEL * NFRAMES / max(1, round(n_same / max(1, n_ev_steps))) / (ms_same / max(n_same, 1) * 1e-3) / 1e9, 2) if n_same else None}},
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "foremanlike_cif 352x288 300f, --intraPeriod 0 (all-intra), QP=16, per GPU (BASELINE configs[1]); steps "
                                "alternate between two disjoint resident 300-frame batches (frames 0-299 and 300-599 of the sequence)",

@@ -873,7 +873,7 @@ template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const Dev
 // rows chained in groups of four (always with the ring; NW covers the widest step: one round)
 template <int NW> void launch_intra8_g4(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
-    const size_t lds = intra8_lds_bytes(g, 4) + (size_t)ring_slots(NW) * 64 * kRingBlocks;
+    const size_t lds = intra8_lds_bytes(g, 4) + (size_t)ring_slots_exact(NW) * 64 * kRingBlocks;
     hipLaunchKernelGGL((k_intra_luma8<NW, true, 4>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
 }
 

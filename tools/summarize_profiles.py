@@ -166,7 +166,80 @@ if old in kernels and "hbm_bytes_per_launch" in kernels[old]:
         out["k_intra_luma_bytes_per_launch"] = kernels[old]["hbm_bytes_per_launch"]
         out["k_intra_luma_algorithmic_bytes_per_launch"] = 300 * (4 * P + 8 * NMB)
         out["k_intra_luma_sq"] = out["k_intra_luma32_sq"]
+# ---- the loaded legs of the bench line (tools/leg_workload.py under rocprofv3): per PASS sums over every launch of the codec's kernels
+def leg_counters(sub):
+    """{kernel: {counter: SUM over dispatches}} and dispatch counts of one PMC pass directory of a leg"""
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    nd = collections.defaultdict(lambda: collections.defaultdict(int))
+    for f in glob.glob(os.path.join(out_dir, sub, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "rocclr" in r["Kernel_Name"]:
+                continue
+            kn = short(r["Kernel_Name"])
+            agg[kn][r["Counter_Name"]] += float(r["Counter_Value"])
+            nd[kn][r["Counter_Name"]] += 1
+    return agg, {k: max(v.values()) for k, v in nd.items()}
+
+
+legs = {}
+for leg, (lp, lnmb, per) in {"config4": (P, NMB, 10), "config4_allintra": (P, NMB, 1), "config5": (1920 * 1088, 8160, 30)}.items():
+    info = None
+    ip = os.path.join(out_dir, f"leg_{leg}.json")
+    if os.path.exists(ip):
+        for l in open(ip):
+            if l.startswith("{"):
+                info = json.loads(l)
+    tot, by = collections.defaultdict(float), {}
+    seen = False
+    for sub in ("a", "b", "c"):
+        agg, nd = leg_counters(f"leg_{leg}_pmc_{sub}")
+        for kn, cs in agg.items():
+            seen = True
+            e = by.setdefault(kn, {})
+            e["launches"] = max(e.get("launches", 0), nd[kn])
+            for cn, v in cs.items():
+                e[cn] = v
+                tot[cn] += v
+    if not seen or not info:
+        continue
+    passes = info["passes_total"]
+    frames = info["frames"]
+    rd = 32 * tot["TCC_EA0_RDREQ_32B"] + 64 * tot["TCC_EA0_RDREQ_64B"] + 128 * tot["TCC_EA0_RDREQ_128B"]
+    wr = tot["WRITE_SIZE"] * 1024
+    f64 = tot["SQ_INSTS_VALU_ADD_F64"] + tot["SQ_INSTS_VALU_MUL_F64"] + tot["SQ_INSTS_VALU_FMA_F64"]
+    n_i = frames if per == 1 else (frames + per - 1) // per
+    n_p = frames - n_i
+    alg = n_i * (6 * lp + 10 * lnmb) + n_p * ((3 * lp + 64 * lnmb) + 84 * lnmb + (7 * lp + lp // 2 + 8 * lnmb))
+    legs[leg] = {"frames": frames, "passes_counted": passes,
+                 "valu_insts_per_pass": int(tot["SQ_INSTS_VALU"] / passes), "fp64_valu_insts_per_pass": int(f64 / passes),
+                 "waiting_share_of_wave_cycles": round(tot["SQ_WAIT_ANY"] / max(tot["SQ_WAVE_CYCLES"], 1), 4),
+                 "valu_active_share_of_wave_cycles": round(tot["SQ_ACTIVE_INST_VALU"] / max(tot["SQ_WAVE_CYCLES"], 1), 4),
+                 "hbm_bytes_per_pass": int((rd + wr) / passes), "read_bytes_per_pass": int(rd / passes), "write_bytes_per_pass": int(wr / passes),
+                 "algorithmic_bytes_per_pass": int(alg), "traffic_over_algorithmic": round((rd + wr) / passes / alg, 3) if rd and wr else None,
+                 "ms_per_pass_of_the_unprofiled_run": info.get("ms_per_pass_here"), "choice": info.get("choice"),
+                 "by_kernel": {kn: {"launches_per_pass": round(e["launches"] / passes, 1), "valu_insts_per_pass": int(e.get("SQ_INSTS_VALU", 0) / passes),
+                                    "fp64_share": round((e.get("SQ_INSTS_VALU_ADD_F64", 0) + e.get("SQ_INSTS_VALU_MUL_F64", 0) + e.get("SQ_INSTS_VALU_FMA_F64", 0)) / max(e.get("SQ_INSTS_VALU", 1), 1), 3),
+                                    "waiting_share": round(e.get("SQ_WAIT_ANY", 0) / max(e.get("SQ_WAVE_CYCLES", 1), 1), 3),
+                                    "hbm_bytes_per_pass": int((32 * e.get("TCC_EA0_RDREQ_32B", 0) + 64 * e.get("TCC_EA0_RDREQ_64B", 0) + 128 * e.get("TCC_EA0_RDREQ_128B", 0) + 1024 * e.get("WRITE_SIZE", 0)) / passes)}
+                               for kn, e in sorted(by.items()) if e.get("SQ_INSTS_VALU")},
+                 "source": f"rocprofv3 --pmc (three passes of their own) on tools/leg_workload.py {leg}: sums over every dispatch / {passes} passes (tools/profile_round.sh)"}
+    st = glob.glob(os.path.join(out_dir, f"leg_{leg}_stats", "**", "*kernel_stats.csv"), recursive=True)
+    if st:
+        shutil.copy(st[0], os.path.join(ROOT, "profiles", f"{tag}_kernel_stats_{leg}.csv"))
+if legs:
+    out["legs"] = legs
+else:
+    try:        # a run without the leg passes keeps what an earlier run of the round measured
+        prev = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if "legs" in prev:
+            out["legs"] = prev["legs"]
+    except Exception:
+        pass
 json.dump(out, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+for leg, e in legs.items():
+    print("leg", leg, {k: v for k, v in e.items() if k not in ("by_kernel", "source", "choice")})
+    for kn, ke in e["by_kernel"].items():
+        print("   ", kn, ke)
 print(json.dumps({"calibration": cal}, indent=1))
 for k, e in kernels.items():
     print(k, {x: e[x] for x in ("launches_seen", "read_bytes_per_launch", "write_bytes_per_launch", "traffic_over_algorithmic", "fp64_share_of_valu_insts",
