@@ -22,7 +22,7 @@ BYTES = 300 * (4 * P + 8 * NMB)
 rows = []
 for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_intra_luma8" in r["Kernel_Name"] and int(r["Grid_Size"]) == 300 * 192:
+        if "k_intra_luma8" in r["Kernel_Name"] and int(r.get("Grid_Size") or r["Grid_Size_X"]) == 300 * 192:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")))
 rows.sort()
 first = SETTLE + warmup

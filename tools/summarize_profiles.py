@@ -178,6 +178,8 @@ def leg_counters(sub):
             kn = short(r["Kernel_Name"])
             agg[kn][r["Counter_Name"]] += float(r["Counter_Value"])
             nd[kn][r["Counter_Name"]] += 1
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":          # the dispatch's own duration, for the clock it ran at
+                agg[kn]["_ns"] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
     return agg, {k: max(v.values()) for k, v in nd.items()}
 
 
@@ -217,6 +219,9 @@ for leg, (lp, lnmb, per) in {"config4": (P, NMB, 10), "config4_allintra": (P, NM
                  "hbm_bytes_per_pass": int((rd + wr) / passes), "read_bytes_per_pass": int(rd / passes), "write_bytes_per_pass": int(wr / passes),
                  "algorithmic_bytes_per_pass": int(alg), "traffic_over_algorithmic": round((rd + wr) / passes / alg, 3) if rd and wr else None,
                  "ms_per_pass_of_the_unprofiled_run": info.get("ms_per_pass_here"), "choice": info.get("choice"),
+                 # GRBM_GUI_ACTIVE sums the 8 XCDs (MI355X_MICROARCH.md, DVFS): cycles / 8 / the dispatches' own time; long dispatches only
+                 "effective_clock_GHz_under_pmc": round(sum(e.get("GRBM_GUI_ACTIVE", 0) for e in by.values() if e.get("_ns", 0) / max(e.get("launches", 1), 1) > 3e5) / 8 /
+                                                        max(sum(e["_ns"] for e in by.values() if e.get("_ns", 0) / max(e.get("launches", 1), 1) > 3e5), 1), 3),
                  "by_kernel": {kn: {"launches_per_pass": round(e["launches"] / passes, 1), "valu_insts_per_pass": int(e.get("SQ_INSTS_VALU", 0) / passes),
                                     "fp64_share": round((e.get("SQ_INSTS_VALU_ADD_F64", 0) + e.get("SQ_INSTS_VALU_MUL_F64", 0) + e.get("SQ_INSTS_VALU_FMA_F64", 0)) / max(e.get("SQ_INSTS_VALU", 1), 1), 3),
                                     "waiting_share": round(e.get("SQ_WAIT_ANY", 0) / max(e.get("SQ_WAVE_CYCLES", 1), 1), 3),
