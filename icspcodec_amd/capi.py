@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("ICSP_LIB") or os.path.join(HERE, "libicsp_hip.so")   
 
 # every symbol include/icsp_hip.h declares
 SYMBOLS = [
-    "icsp_create", "icsp_destroy", "icsp_strerror", "icsp_device_count", "icsp_last_error", "icsp_encode_gop", "icsp_upload",
+    "icsp_create", "icsp_destroy", "icsp_strerror", "icsp_device_count", "icsp_last_error", "icsp_encode_gop", "icsp_encode_gop_packed", "icsp_upload",
     "icsp_encode_resident", "icsp_sync", "icsp_download", "icsp_device_view", "icsp_download_debug",
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
@@ -62,6 +62,7 @@ def load() -> C.CDLL:
         lib.icsp_create.argtypes = [C.POINTER(vp), C.POINTER(Params), C.c_int, C.c_int]
         lib.icsp_destroy.argtypes = [vp]
         lib.icsp_encode_gop.argtypes = [vp, vp, C.c_int, vp, vp, vp, vp, vp]
+        lib.icsp_encode_gop_packed.argtypes = [vp, vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]
         lib.icsp_upload.argtypes = [vp, vp, C.c_int, C.c_int]
         lib.icsp_encode_resident.argtypes = [vp, C.c_int, C.c_int]
         lib.icsp_sync.argtypes = [vp]
@@ -149,6 +150,32 @@ def finish_image(width, height, qp_dc, qp_ac, intra_period, image: np.ndarray, t
     return image[: n.value].tobytes()
 
 
+def host_alloc_array(shape, dtype) -> np.ndarray:
+    """A numpy array in pinned host memory (icsp_host_alloc); release it with host_free_array."""
+    lib = load()
+    lib.icsp_host_alloc.restype = C.c_void_p
+    lib.icsp_host_alloc.argtypes = [C.c_size_t]
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = lib.icsp_host_alloc(max(nbytes, 1))
+    if not p:
+        raise IcspError("icsp_host_alloc failed")
+    buf = (C.c_uint8 * max(nbytes, 1)).from_address(p)
+    a = np.frombuffer(buf, dtype=np.uint8, count=nbytes).view(dtype).reshape(shape)
+    _pinned[a.ctypes.data] = p
+    return a
+
+
+def host_free_array(a: np.ndarray):
+    lib = load()
+    lib.icsp_host_free.argtypes = [C.c_void_p]
+    p = _pinned.pop(a.ctypes.data, None)
+    if p:
+        lib.icsp_host_free(p)
+
+
+_pinned = {}
+
+
 def host_register(a: np.ndarray, read_only=False) -> bool:
     """Pins the array's memory for DMA (icsp_host_register); False when the runtime refuses."""
     return load().icsp_host_register(_vp(a), a.nbytes, 1 if read_only else 0) == 0
@@ -231,14 +258,28 @@ class Encoder:
                     mpm=np.zeros((n, self.nmb, 4), np.uint8), mvd=np.zeros((n, self.nmb, 2), np.int8),
                     recon=np.zeros((n, self.fsz), np.uint8))
 
-    def encode(self, yuv: np.ndarray) -> dict:
-        """icsp_encode_gop: host frames in, host results out."""
-        y = np.ascontiguousarray(yuv, np.uint8).reshape(-1, self.fsz)
+    def encode(self, yuv: np.ndarray, out: dict | None = None) -> dict:
+        """icsp_encode_gop: host frames in, host results out (into `out`, a dict like the one returned, when given: arrays
+        the caller keeps, possibly pinned)."""
+        y = yuv if (isinstance(yuv, np.ndarray) and yuv.dtype == np.uint8 and yuv.flags.c_contiguous) else np.ascontiguousarray(yuv, np.uint8)
+        y = y.reshape(-1, self.fsz)
         n = y.shape[0]
-        o = self._alloc(n)
+        o = out if out is not None else self._alloc(n)
         self._chk(self.lib.icsp_encode_gop(self.ctx, _vp(y), n, _vp(o["levels"]), _vp(o["acflag"]), _vp(o["mpm"]),
                                            _vp(o["mvd"]), _vp(o["recon"])), "icsp_encode_gop")
         return o
+
+    def encode_packed(self, yuv: np.ndarray, recon: np.ndarray | None = None, body: np.ndarray | None = None):
+        """icsp_encode_gop_packed: host frames in; the packed body (and the reconstruction, if an array is given) out.
+        Returns (body bytes as uint8 array, bits)."""
+        y = np.ascontiguousarray(yuv, np.uint8).reshape(-1, self.fsz)
+        n = y.shape[0]
+        if body is None:
+            body = np.empty(self.lib.icsp_bitstream_bound(C.byref(self.params), n), np.uint8)
+        bits = C.c_uint64(0)
+        self._chk(self.lib.icsp_encode_gop_packed(self.ctx, _vp(y), n, _vp(recon) if recon is not None else None, _vp(body), body.nbytes,
+                                                  C.byref(bits)), "icsp_encode_gop_packed")
+        return body[: (bits.value + 7) // 8], bits.value
 
     def upload(self, yuv: np.ndarray, first=0):
         y = np.ascontiguousarray(yuv, np.uint8).reshape(-1, self.fsz)

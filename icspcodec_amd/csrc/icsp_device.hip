@@ -27,8 +27,12 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
@@ -397,6 +401,13 @@ struct icsp_ctx {
     int pk_first, pk_n;               // the range icsp_pack_count last measured (-1: none)
     unsigned long long pk_total;      //   and its bits
     uint8_t* d_frames;
+    // icsp_encode_gop's transfer pipeline: two pinned staging buffers each way for caller memory that is not pinned (allocated on
+    // first use, sized to a chunk), the event a chunk's kernels are waited for by, helper threads for the staging copies
+    uint8_t* gop_stage_in[2];
+    uint8_t* gop_stage_out[2];
+    size_t gop_stage_in_cap, gop_stage_out_cap;
+    hipEvent_t gop_ev[2][2 + 3];          // per chunk in flight (two): one event per stream of the context (stream, stream2, group streams)
+    struct CopyPool* gop_pool;
     bool keep_coef, profiling;
     unsigned prof_mask;               // which kernels get HIP events (icsp_profile_enable's argument, bit k = kernel k)
     std::vector<EvPair> ev_pending;
@@ -450,6 +461,7 @@ void build_me_tables(MeTables& t)
 }
 
 int collect_profile(icsp_ctx* ctx);
+void gop_release(icsp_ctx* ctx);
 
 int poison(icsp_ctx* ctx, const char* what, hipError_t e)
 {
@@ -941,6 +953,85 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
 
 } // namespace
 
+// Helper threads for the staging copies of icsp_encode_gop (caller memory that is not pinned goes through pinned buffers; one
+// thread copies 10-12 GB/s, the link moves 57 each way).  run(n, f) executes f(0..n-1) on the caller and the helpers and
+// returns when all are done.  One job at a time (the context's calls are serialised by contract; the uploader thread of a
+// call uses a pool of its own).
+struct CopyPool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_job, cv_done;
+    std::function<void(int)> job;
+    int n_items = 0, next = 0, running = 0, gen = 0;
+    bool stop = false;
+    explicit CopyPool(int helpers)
+    {
+        for (int k = 0; k < helpers; k++) th.emplace_back([this] { loop(); });
+    }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> l(m); stop = true; }
+        cv_job.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void loop()
+    {
+        int seen = 0;
+        std::unique_lock<std::mutex> l(m);
+        for (;;) {
+            cv_job.wait(l, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            work(l);
+        }
+    }
+    void work(std::unique_lock<std::mutex>& l)      // called with the lock held
+    {
+        while (next < n_items) {
+            const int k = next++;
+            running++;
+            l.unlock();
+            job(k);
+            l.lock();
+            running--;
+        }
+        if (running == 0) cv_done.notify_all();
+    }
+    void run(int n, std::function<void(int)> f)
+    {
+        std::unique_lock<std::mutex> l(m);
+        job = std::move(f); n_items = n; next = 0; gen++;
+        cv_job.notify_all();
+        work(l);
+        cv_done.wait(l, [&] { return next >= n_items && running == 0; });
+    }
+    // dst[0, bytes) = src[0, bytes) in slices of at least 1 MB over all threads
+    void copy(void* dst, const void* src, size_t bytes)
+    {
+        const size_t slices = std::max<size_t>(1, std::min<size_t>(th.size() + 1, bytes >> 20));
+        if (slices == 1) { memcpy(dst, src, bytes); return; }
+        const size_t per = ((bytes + slices - 1) / slices + 4095) & ~(size_t)4095;
+        run((int)slices, [=](int k) {
+            const size_t o = (size_t)k * per;
+            if (o < bytes) memcpy((char*)dst + o, (const char*)src + o, std::min(per, bytes - o));
+        });
+    }
+};
+
+namespace {
+void gop_release(icsp_ctx* ctx)
+{
+    delete ctx->gop_pool; ctx->gop_pool = nullptr;
+    for (int k = 0; k < 2; k++) {
+        if (ctx->gop_stage_in[k]) (void)hipHostFree(ctx->gop_stage_in[k]);
+        if (ctx->gop_stage_out[k]) (void)hipHostFree(ctx->gop_stage_out[k]);
+        for (auto& e : ctx->gop_ev[k]) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        ctx->gop_stage_in[k] = ctx->gop_stage_out[k] = nullptr;
+    }
+    ctx->gop_stage_in_cap = ctx->gop_stage_out_cap = 0;
+}
+} // namespace
+
 // ================================================================================================ C ABI
 extern "C" {
 
@@ -1104,6 +1195,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(&ctx->pk, 0, sizeof(ctx->pk)); ctx->pk_cap = 0; ctx->pk_host = nullptr; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
     ctx->stream = nullptr; ctx->stream2 = nullptr; ctx->ev_fork = nullptr; ctx->ev_join = nullptr;
     ctx->up_stream = nullptr; ctx->down_stream = nullptr;
+    ctx->gop_stage_in[0] = ctx->gop_stage_in[1] = ctx->gop_stage_out[0] = ctx->gop_stage_out[1] = nullptr;
+    ctx->gop_stage_in_cap = ctx->gop_stage_out_cap = 0; memset(ctx->gop_ev, 0, sizeof(ctx->gop_ev)); ctx->gop_pool = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
     ctx->p_dirty = false; ctx->sticky = 0;
     memset(ctx->flight, 0, sizeof(ctx->flight));
@@ -1201,6 +1294,7 @@ int icsp_destroy(icsp_ctx_t* ctx)
                      ctx->pk.chunk_bits, ctx->pk.chunk_base, ctx->pk.out };
     for (void* q : bufs) if (q) (void)hipFree(q);
     if (ctx->pk_host) (void)hipHostFree(ctx->pk_host);
+    gop_release(ctx);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     for (auto& f : ctx->flight) { if (f.ev_done) (void)hipEventDestroy(f.ev_done); for (int k = 0; k < kMaxPGroups; k++) if (f.ev_p1[k]) (void)hipEventDestroy(f.ev_p1[k]); }
@@ -1581,11 +1675,198 @@ int icsp_prepare(icsp_ctx_t* ctx)
     return rc;
 }
 
+namespace {
+// Is [p, p + bytes) pinned host memory (hipHostMalloc / hipHostRegister), i.e. can a DMA engine reach it directly?
+bool host_pinned(const void* p, size_t bytes)
+{
+    if (!p || !bytes) return true;
+    hipPointerAttribute_t a;
+    for (const char* q : { (const char*)p, (const char*)p + bytes - 1 }) {
+        memset(&a, 0, sizeof(a));
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }      // unknown to the runtime: pageable
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+// The one-call host path as a pipeline: the frames go up chunk by chunk (whole GOPs) on the device's upload stream from a helper
+// thread, every chunk is encoded as soon as it is there, and its levels and reconstruction come down on the device's download
+// stream while the next chunk is being encoded and the one after it uploaded -- transfers in both directions and kernels side by
+// side, which a plain upload / encode / download sequence (18.8 k CIF frames/s, round 3) never has.  Caller memory that is pinned
+// (icsp_host_alloc, icsp_host_register) is the DMA source / target itself; memory that is not goes through two pinned staging
+// buffers each way, filled and emptied by a few helper threads (one thread copies 10-12 GB/s, the link moves 57).  The small arrays
+// (ACflags, mode bits, vector differences: 12 bytes per macroblock) come down once at the end.
+// pack: instead of (or beside) the levels the caller gets the packed body (icsp_pack_bits) -- 4 % of the bytes.
+// Replaces the loop of single_thread_encoding (ENC:217-245) + YCbCrLoad's frames (ENC:247-283) as input; same bytes as
+// icsp_upload + icsp_encode_resident + icsp_download.
+int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* levels, uint8_t* acflag, uint8_t* mpm, int8_t* mvd, uint8_t* recon,
+                 uint8_t* body, size_t body_cap, uint64_t* nbits)
+{
+    ENTER(ctx);
+    if (!yuv) return ICSP_ERR_UNENOUGH_PARAM;
+    if (body && !nbits) return ICSP_ERR_UNENOUGH_PARAM;
+    if (int rc = check_range(ctx, 0, n)) return rc;
+    if (nbits) *nbits = 0;
+    if (n == 0) return ICSP_OK;
+    HIPCHK(hipSetDevice(ctx->device));
+    const Geo& g = ctx->g;
+    const size_t fsz = (size_t)g.fsz, nmb = (size_t)g.nmb, lvf = nmb * 384 * sizeof(int16_t);       // bytes per frame: input / recon, levels
+    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
+    // Chunks of whole GOPs.  The downloads carry three times the bytes of the uploads and set the pace, so the first chunk is
+    // small -- the download stream starts early -- and every next one twice as large (its upload and its kernels, a quarter of a
+    // millisecond for CIF I frames whatever their number, then fit under the download of the one before), up to about 32 MB of
+    // results, from where a transfer runs at the link's rate anyway (300 CIF frames: 19 + 38 + 76 + 67 + ... against five chunks of
+    // 67: 89 k -> 100 k frames/s from pinned memory).
+    const size_t out_per_frame = (levels ? lvf : 0) + (recon ? fsz : 0) + fsz / 4;                 // (never 0)
+    long long cf = (long long)(((size_t)32 << 20) / out_per_frame);                                // frames of the largest chunk
+    cf = std::max<long long>(L, (cf + L - 1) / L * L);
+    if (cf > n) cf = n;
+    std::vector<int> c_first, c_n;
+    {
+        long long sz = std::max<long long>(L, ((n + 15) / 16 + L - 1) / L * L);
+        for (long long f = 0; f < n; ) {
+            const long long k = std::min<long long>(std::min(sz, cf), n - f);
+            c_first.push_back((int)f); c_n.push_back((int)k);
+            f += k;
+            sz *= 2;
+        }
+        // (a last chunk of a GOP or two is not worth a turn of its own)
+        if (c_n.size() >= 2 && c_n.back() < c_n[c_n.size() - 2] / 4 && c_n[c_n.size() - 2] + c_n.back() <= cf + cf / 4) {
+            c_n[c_n.size() - 2] += c_n.back(); c_n.pop_back(); c_first.pop_back();
+        }
+    }
+    const int nc = (int)c_n.size();
+    for (int k : c_n) cf = std::max<long long>(cf, k);                                             // staging buffers hold the largest
+    if (nc == 1 && !ctx->up_stream) {
+        // one chunk: nothing to overlap, and the shared transfer streams cost tens of milliseconds to set up
+        if (int rc = icsp_upload(ctx, yuv, 0, n)) return rc;
+        if (int rc = icsp_encode_resident(ctx, 0, n)) return rc;
+        if (int rc = icsp_download(ctx, 0, n, levels, acflag, mpm, mvd, recon)) return rc;
+        return body ? icsp_pack_bits(ctx, 0, n, body, body_cap, nbits) : ICSP_OK;
+    }
+    if (!ctx->up_stream) { if (int rc = icsp_copy_streams(ctx, 1)) return rc; }          // (once per device and process: two DMA engines)
+    if (int rc = join_all(ctx)) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));                    // whatever still reads the frame store or writes the results
+    for (int k = 0; k < 2; k++) for (auto& e : ctx->gop_ev[k]) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const bool in_direct = host_pinned(yuv, (size_t)n * fsz);
+    const bool lv_direct = host_pinned(levels, (size_t)n * lvf), rc_direct = host_pinned(recon, (size_t)n * fsz);
+    const size_t need_in = in_direct ? 0 : (size_t)cf * fsz;
+    const size_t need_out = ((levels && !lv_direct) ? (size_t)cf * lvf : 0) + ((recon && !rc_direct) ? (size_t)cf * fsz : 0);
+    if (need_in > ctx->gop_stage_in_cap || need_out > ctx->gop_stage_out_cap) {
+        for (int k = 0; k < 2; k++) {
+            if (need_in > ctx->gop_stage_in_cap) {
+                if (ctx->gop_stage_in[k]) (void)hipHostFree(ctx->gop_stage_in[k]);
+                ctx->gop_stage_in[k] = nullptr;
+                if (hipHostMalloc((void**)&ctx->gop_stage_in[k], need_in, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->gop_stage_in[k] = nullptr; ctx->gop_stage_in_cap = 0; ctx->err = "hipHostMalloc staging (in)"; return ICSP_ERR_MEM_ALLOC; }
+            }
+            if (need_out > ctx->gop_stage_out_cap) {
+                if (ctx->gop_stage_out[k]) (void)hipHostFree(ctx->gop_stage_out[k]);
+                ctx->gop_stage_out[k] = nullptr;
+                if (hipHostMalloc((void**)&ctx->gop_stage_out[k], need_out, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->gop_stage_out[k] = nullptr; ctx->gop_stage_out_cap = 0; ctx->err = "hipHostMalloc staging (out)"; return ICSP_ERR_MEM_ALLOC; }
+            }
+        }
+        ctx->gop_stage_in_cap = std::max(ctx->gop_stage_in_cap, need_in); ctx->gop_stage_out_cap = std::max(ctx->gop_stage_out_cap, need_out);
+    }
+    const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
+    if ((need_in || need_out) && !ctx->gop_pool) ctx->gop_pool = new (std::nothrow) CopyPool((int)std::min(5u, hw / 2));
+    if ((need_in || need_out) && !ctx->gop_pool) return ICSP_ERR_MEM_ALLOC;
+
+    // ---- uploader thread: chunk after chunk onto the device's upload stream (one transfer at a time per stream: copy_up's rule)
+    std::mutex um; std::condition_variable ucv;
+    int uploaded = 0, up_rc = 0;
+    std::atomic<bool> cancel{ false };
+    std::thread uploader([&] {
+        if (hipSetDevice(ctx->device) != hipSuccess) { (void)hipGetLastError(); std::lock_guard<std::mutex> l(um); up_rc = ICSP_ERR_HIP; ucv.notify_all(); return; }
+        CopyPool* pool = need_in ? new (std::nothrow) CopyPool(2) : nullptr;       // its own helpers: the caller's pool empties the other direction meanwhile
+        for (int c = 0; c < nc && !cancel.load(); c++) {
+            const size_t f0 = (size_t)c_first[c], cn = (size_t)c_n[c];
+            const uint8_t* src = yuv + f0 * fsz;
+            if (!in_direct) {
+                if (pool) pool->copy(ctx->gop_stage_in[c & 1], src, cn * fsz); else memcpy(ctx->gop_stage_in[c & 1], src, cn * fsz);
+                src = ctx->gop_stage_in[c & 1];
+            }
+            bool ok;
+            {
+                std::lock_guard<std::mutex> t(g_up_turn[ctx->device & 63]);
+                ok = hipMemcpyAsync(ctx->d_frames + f0 * fsz, src, cn * fsz, hipMemcpyHostToDevice, ctx->up_stream) == hipSuccess &&
+                     hipStreamSynchronize(ctx->up_stream) == hipSuccess;
+            }
+            std::lock_guard<std::mutex> l(um);
+            if (!ok) { (void)hipGetLastError(); up_rc = ICSP_ERR_HIP; ucv.notify_all(); break; }
+            uploaded = c + 1;
+            ucv.notify_all();
+        }
+        delete pool;
+    });
+    struct Joiner { std::thread& t; std::atomic<bool>& c; ~Joiner() { c.store(true); if (t.joinable()) t.join(); } } joiner{ uploader, cancel };
+
+    // ---- this thread: encode chunk c, then bring chunk c-1 down while c runs; the staged results of c-2 leave meanwhile
+    int rc = 0;
+    auto stage_off_recon = [&](size_t cn) { return (levels && !lv_direct) ? cn * lvf : (size_t)0; };
+    auto unstage = [&](int c) {                                                    // staging buffer -> the caller's arrays
+        const size_t f0 = (size_t)c_first[c], cn = (size_t)c_n[c];
+        const uint8_t* st = ctx->gop_stage_out[c & 1];
+        if (levels && !lv_direct) ctx->gop_pool->copy((char*)levels + f0 * lvf, st, cn * lvf);
+        if (recon && !rc_direct) ctx->gop_pool->copy(recon + f0 * fsz, st + stage_off_recon(cn), cn * fsz);
+    };
+    for (int c = 0; c <= nc && !rc; c++) {
+        if (c < nc) {
+            {
+                std::unique_lock<std::mutex> l(um);
+                ucv.wait(l, [&] { return uploaded > c || up_rc; });
+                if (up_rc) { rc = up_rc; ctx->err = "icsp_encode_gop: upload failed"; break; }
+            }
+            const size_t f0 = (size_t)c_first[c], cn = (size_t)c_n[c];
+            if ((rc = encode_range(ctx, (int)f0, (int)cn))) break;
+            // "chunk c is through": an event behind what each stream of the context carries now -- everything of chunk c, nothing
+            // of chunk c + 1 -- instead of a join, so that the chunks' kernels overlap the way encode_range lets disjoint ranges
+            hipStream_t sts[5] = { ctx->stream, ctx->stream2, ctx->pstream[0], ctx->pstream[1], ctx->pstream[2] };
+            for (int k = 0; k < 5 && !rc; k++)
+                if (sts[k] && (k < 2 || sts[k] != ctx->stream) && hipEventRecord(ctx->gop_ev[c & 1][k], sts[k]) != hipSuccess) rc = poison(ctx, "hipEventRecord", hipGetLastError());
+            if (rc) break;
+        }
+        if (c >= 1) {
+            const int d = c - 1;
+            const size_t f0 = (size_t)c_first[d], cn = (size_t)c_n[d];
+            {
+                hipStream_t sts[5] = { ctx->stream, ctx->stream2, ctx->pstream[0], ctx->pstream[1], ctx->pstream[2] };
+                for (int k = 0; k < 5 && !rc; k++)     // (an event never recorded counts as complete; a stream created since then carries later chunks only)
+                    if (sts[k] && hipEventSynchronize(ctx->gop_ev[d & 1][k]) != hipSuccess) { rc = ICSP_ERR_HIP; ctx->err = "hipEventSynchronize"; (void)hipGetLastError(); }
+                if (rc) break;
+            }
+            {
+                std::lock_guard<std::mutex> t(g_down_turn[ctx->device & 63]);
+                hipStream_t ds = ctx->down_stream;
+                uint8_t* st = ctx->gop_stage_out[d & 1];
+                hipError_t e = hipSuccess;
+                if (levels) e = hipMemcpyAsync(lv_direct ? (void*)((char*)levels + f0 * lvf) : (void*)st, (const char*)ctx->b.levels + f0 * lvf, cn * lvf, hipMemcpyDeviceToHost, ds);
+                if (e == hipSuccess && recon) e = hipMemcpyAsync(rc_direct ? recon + f0 * fsz : st + stage_off_recon(cn), ctx->b.recon + f0 * fsz, cn * fsz, hipMemcpyDeviceToHost, ds);
+                if (e == hipSuccess && d >= 1 && need_out) unstage(d - 1);        // (the other staging buffer, beside the transfer)
+                if (e == hipSuccess) e = hipStreamSynchronize(ds);
+                if (e != hipSuccess) { (void)hipGetLastError(); rc = ICSP_ERR_HIP; ctx->err = std::string("icsp_encode_gop download: ") + hipGetErrorString(e); break; }
+            }
+        }
+    }
+    cancel.store(true);
+    if (uploader.joinable()) uploader.join();
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    if (need_out) unstage(nc - 1);
+    // the small arrays of the whole range, and the packed body
+    if (acflag || mpm || mvd) { if (int r2 = icsp_download(ctx, 0, n, nullptr, acflag, mpm, mvd, nullptr)) return r2; }
+    if (body) { if (int r2 = icsp_pack_bits(ctx, 0, n, body, body_cap, nbits)) return r2; }
+    return ICSP_OK;
+}
+} // namespace
+
 int icsp_encode_gop(icsp_ctx_t* ctx, const uint8_t* yuv, int n, int16_t* levels, uint8_t* acflag, uint8_t* mpm, int8_t* mvd, uint8_t* recon)
 {
-    if (int rc = icsp_upload(ctx, yuv, 0, n)) return rc;
-    if (int rc = icsp_encode_resident(ctx, 0, n)) return rc;
-    return icsp_download(ctx, 0, n, levels, acflag, mpm, mvd, recon);
+    return gop_pipeline(ctx, yuv, n, levels, acflag, mpm, mvd, recon, nullptr, 0, nullptr);
+}
+
+int icsp_encode_gop_packed(icsp_ctx_t* ctx, const uint8_t* yuv, int n, uint8_t* recon, uint8_t* body, size_t cap, uint64_t* nbits)
+{
+    if (!body || !nbits) return ICSP_ERR_UNENOUGH_PARAM;
+    return gop_pipeline(ctx, yuv, n, nullptr, nullptr, nullptr, nullptr, recon, body, cap, nbits);
 }
 
 // Scheduling knobs of one context (what ICSP_P_GROUPS / ICSP_I_GROUPS set for every context of the process): 0 keeps a value.
@@ -1753,6 +2034,9 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
+    ctx->gop_stage_in[0] = ctx->gop_stage_in[1] = ctx->gop_stage_out[0] = ctx->gop_stage_out[1] = nullptr;
+    ctx->gop_stage_in_cap = ctx->gop_stage_out_cap = 0; memset(ctx->gop_ev, 0, sizeof(ctx->gop_ev)); ctx->gop_pool = nullptr;
+    ctx->force_intra_group = 0; ctx->intra_waves_g4 = 0; ctx->last_rowgroup = 0;
     ctx->s2_dirty = ctx->st_ahead = ctx->always_sync = ctx->p_dirty = false;
     ctx->keep_coef = ctx->profiling = false; ctx->prof_mask = 0;
     poison(ctx, "icsp_debug_poisoned_context", hipErrorUnknown);

@@ -94,6 +94,19 @@ const char* icsp_last_error(const icsp_ctx_t* ctx);   /* text of the last HIP fa
  *      All pointers are caller-owned host memory; any output pointer may be NULL (skipped). ----- */
 int icsp_encode_gop(icsp_ctx_t* ctx, const uint8_t* yuv420_in, int n,
                     int16_t* levels, uint8_t* acflag, uint8_t* mpm_mode, int8_t* mvd, uint8_t* recon);
+/* Inside the call the frames are cut into chunks of whole GOPs (about 32 MB of results each) that go up, are encoded and come
+ * down as a pipeline: uploads, kernels and downloads of neighbouring chunks run side by side on the device's two transfer
+ * streams (icsp_copy_streams is switched on for the context by the first multi-chunk call; once per device and process that
+ * costs some tens of milliseconds).  Arrays in pinned memory (icsp_host_alloc, or the caller's own memory after
+ * icsp_host_register -- the frame buffers YCbCrLoad allocates once per clip, ENC:247-283, are the natural candidates) are read
+ * and written by DMA directly: the call then runs at the link's rate; other memory goes through pinned staging buffers of the
+ * context with a few helper threads.  Same bytes either way.
+ *
+ * icsp_encode_gop_packed: the same, but instead of the levels and the side arrays the caller gets the PACKED BODY of the frames
+ * (what icsp_pack_bits returns: `*nbits` bits, to be framed by icsp_bitstream_assemble / _begin, _place, _end) -- makebitstream
+ * (ENC.h:310, callers ENC:222, 242) needs nothing else, and it is 4 % of the levels' bytes.  recon may be NULL. */
+int icsp_encode_gop_packed(icsp_ctx_t* ctx, const uint8_t* yuv420_in, int n, uint8_t* recon,
+                           uint8_t* body, size_t body_cap, uint64_t* nbits);
 
 /* ---- resident path (inputs already in HBM when the timed region starts) --------------------- */
 int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv420_in, int first_frame, int n);   /* H2D into slots [first, first+n) */

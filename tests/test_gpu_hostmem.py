@@ -158,3 +158,105 @@ def test_upload_sync_from_a_second_thread_beside_the_downloads():
     enc.close()
     for k in want:
         assert np.array_equal(got[k], want[k]), k
+
+
+# ---- icsp_encode_gop as a pipeline (chunks of whole GOPs: upload, kernels and download side by side): pageable, pinned and
+#      registered caller memory give the bytes of upload + encode_resident + download
+def _plain(clip, q, period):
+    n = clip.shape[0]
+    ref = capi.Encoder(W, H, q, q, period, max_frames=n)
+    ref.upload(clip)
+    ref.encode_resident(0, n)
+    want = ref.download(0, n)
+    body, bits = ref.pack_bits(0, n)
+    body = body.copy()
+    ref.close()
+    return want, body, bits
+
+
+def _same(got, want, tag):
+    for k in ("levels", "acflag", "mpm", "mvd", "recon"):
+        assert np.array_equal(np.asarray(got[k]).reshape(want[k].shape), want[k]), tag + k
+
+
+@pytest.mark.parametrize("period,n", [(0, 230), (10, 205), (7, 150)])
+@pytest.mark.parametrize("mem", ["pageable", "pinned", "registered"])
+def test_encode_gop_pipeline_matches_the_resident_path(mem, period, n):
+    q = 16 if period == 0 else 8
+    clip = clipgen.synth_clip("stefanlike" if period else "foremanlike", n)
+    want, body, bits = _plain(clip, q, period)
+    nmb, fsz = (W // 16) * (H // 16), W * H * 3 // 2
+    shapes = dict(levels=((n, nmb, 6, 64), np.int16), acflag=((n, nmb, 6), np.uint8), mpm=((n, nmb, 4), np.uint8),
+                  mvd=((n, nmb, 2), np.int8), recon=((n, fsz), np.uint8))
+    enc = capi.Encoder(W, H, q, q, period, max_frames=n)
+    if mem == "pinned":
+        src = capi.host_alloc_array(clip.shape, np.uint8)
+        src[:] = clip
+        out = {k: capi.host_alloc_array(s, d) for k, (s, d) in shapes.items()}
+    else:
+        src = clip.copy()
+        out = {k: np.full(s, 0x55, d) for k, (s, d) in shapes.items()}
+        if mem == "registered":
+            assert capi.host_register(src, read_only=True)
+            for a in out.values():
+                assert capi.host_register(a)
+    for a in out.values():
+        a.reshape(-1).view(np.uint8)[:] = 0x55
+    try:
+        for rep in range(2):                                  # the second call finds the staging buffers and streams in place
+            got = enc.encode(src, out=out)
+            _same(got, want, f"{mem} p={period} n={n} rep={rep}: ")
+        # outputs the caller does not want
+        part = dict(out)
+        for a in out.values():
+            a.reshape(-1).view(np.uint8)[:] = 0
+        rc = enc.lib.icsp_encode_gop(enc.ctx, capi._vp(src), n, None, None, capi._vp(out["mpm"]), None, capi._vp(out["recon"]))
+        assert rc == 0
+        assert np.array_equal(out["recon"], want["recon"]) and np.array_equal(out["mpm"], want["mpm"]) and not out["levels"].any()
+        # the packed form: body bits + reconstruction only
+        out["recon"][:] = 0
+        b2, nb2 = enc.encode_packed(src, recon=out["recon"])
+        assert nb2 == bits and np.array_equal(b2, body[: len(b2)]) and np.array_equal(out["recon"], want["recon"])
+        b3, nb3 = enc.encode_packed(src)
+        assert nb3 == bits and np.array_equal(b3, body[: len(b3)])
+        # and the resident calls still work on a context whose transfers now run on the shared streams
+        enc.upload(clip[:20])
+        enc.encode_resident(0, 20)
+        assert np.array_equal(enc.download(0, 20, what=("recon",))["recon"], want["recon"][:20])
+    finally:
+        enc.close()
+        if mem == "registered":
+            capi.host_unregister(src)
+            for a in out.values():
+                capi.host_unregister(a)
+        if mem == "pinned":
+            capi.host_free_array(src)
+            for a in out.values():
+                capi.host_free_array(a)
+
+
+def test_encode_gop_small_batches_take_the_single_chunk_path():
+    for period, n in ((0, 5), (4, 9), (10, 3)):
+        clip = clipgen.synth_clip("mobilelike", n)
+        want, body, bits = _plain(clip, 8, period)
+        enc = capi.Encoder(W, H, 8, 8, period, max_frames=n)
+        _same(enc.encode(clip), want, f"p={period} n={n}: ")
+        b, nb = enc.encode_packed(clip)
+        enc.close()
+        assert nb == bits and np.array_equal(b, body[: len(b)])
+
+
+def test_encode_gop_large_frames_pipeline():
+    """1088p: a chunk is one GOP; three GOPs, ragged last one"""
+    w, h, period, n = 1920, 1088, 4, 10
+    clip = clipgen.synth_clip("tablelike", n, width=w, height=h)
+    ref = capi.Encoder(w, h, 16, 16, period, max_frames=n)
+    ref.upload(clip)
+    ref.encode_resident(0, n)
+    want = ref.download(0, n)
+    ref.close()
+    enc = capi.Encoder(w, h, 16, 16, period, max_frames=n)
+    got = enc.encode(clip)
+    enc.close()
+    for k in ("levels", "acflag", "mpm", "mvd", "recon"):
+        assert np.array_equal(got[k], want[k]), k
