@@ -588,11 +588,23 @@ def main():
                     return subprocess.run([enc_bin] + args, cwd=tmp, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
                 except subprocess.TimeoutExpired as e:
                     return subprocess.CompletedProcess(e.cmd, "timeout", e.stdout or b"", None)
-            r = run_enc(["-i", os.path.basename(path), "-n", str(NFRAMES), "-q", "16", "--intraPeriod", "0", "--stats"])
-            wall = time.perf_counter() - t0
+            # three runs, a second apart (hsa_init takes 0.15-0.25 s instead of 0.06 when the previous GPU process exited a moment
+            # ago).  The FIRST is the first run of the program on this box: before round 4 it paid 0.14 s of page
+            # faults into the HIP runtime's libraries from a cold disk (tools/cold_cache.sh), which icsp_enc now reads ahead.
+            walls = []
+            for _ in range(3):
+                time.sleep(1.0)
+                t0 = time.perf_counter()
+                r = run_enc(["-i", os.path.basename(path), "-n", str(NFRAMES), "-q", "16", "--intraPeriod", "0", "--stats"])
+                walls.append(time.perf_counter() - t0)
+                if _ == 0:
+                    first_out = r.stdout.decode(errors="replace")
+            wall = sorted(walls)[1]
             out = r.stdout.decode(errors="replace")
             e2e = {"workload": "icsp_enc: foremanlike 300 f file -> .bin + test_yuv.yuv (tmpfs), all-intra QP16", "rc": r.returncode,
-                   "wall_fps_incl_process_start_and_hip_init": round(NFRAMES / wall, 1)}
+                   "wall_fps_incl_process_start_and_hip_init": round(NFRAMES / wall, 1),
+                   "wall_is": "median of three runs of the program a second apart (process start to exit, measured by the parent)",
+                   "wall_s_of_the_three_runs": [round(w, 4) for w in walls]}
 
             def stats(text):
                 for line in text.splitlines():
@@ -603,6 +615,7 @@ def main():
                             return None
                 return None
             e2e["stats"] = stats(out)
+            e2e["stats_first_run_on_this_box"] = {k: v for k, v in (stats(first_out) or {}).items() if k in ("init_s", "hip_start_s", "setup_worker0", "map_files_s", "encode_s")}
             ref = next(s for s in golden if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == ("foremanlike", 300, 16, 0) and "bin_sha256" in s)
             binf = [f for f in os.listdir(tmp) if f.endswith(".bin")]
             e2e["bin_equals_reference"] = bool(binf) and hashlib.sha256(open(os.path.join(tmp, binf[0]), "rb").read()).hexdigest() == ref["bin_sha256"]
@@ -619,6 +632,7 @@ def main():
                 best = None
                 rates = []
                 for _ in range(2):
+                    time.sleep(1.0)
                     t0 = time.perf_counter()
                     r = run_enc(["-i", os.path.basename(long_path), "-n", "3000", "-q", "16", "--intraPeriod", str(period), "--stats"])
                     wall = time.perf_counter() - t0

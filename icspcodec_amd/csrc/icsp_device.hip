@@ -1167,9 +1167,15 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
         p->qp_dc <= 0 || p->qp_ac <= 0 || p->qp_dc > 255 || p->qp_ac > 255 ||      /* one header byte each (ENC.h:207-208) */
         p->intra_period < 0 || max_frames <= 0)
         return ICSP_ERR_UNCORRECT_PARAM;
+    // ICSP_TRACE_CREATE=1: where the set-up time goes, phase by phase, on stderr (tools/cold_first.sh)
+    const bool trace = getenv("ICSP_TRACE_CREATE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tph = tnow();
+    auto phase = [&](const char* what) { if (trace) { const double t = tnow(); fprintf(stderr, "[icsp_create] %-28s %8.3f ms\n", what, (t - tph) * 1e3); tph = t; } };
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ICSP_ERR_NO_DEVICE;
     if (hipSetDevice(device_id) != hipSuccess) return ICSP_ERR_NO_DEVICE;
+    phase("device count + set device");
     icsp_ctx* ctx = new (std::nothrow) icsp_ctx();
     if (!ctx) return ICSP_ERR_MEM_ALLOC;
     ctx->p = *p; ctx->device = device_id; ctx->max_frames = max_frames;
@@ -1226,6 +1232,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     int prio_lo = 0, prio_hi = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { (void)hipGetLastError(); prio_lo = prio_hi = 0; }
     if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
+    phase("priority range + stream");
     ctx->prio_lo = prio_lo;            // stream2 is created by the first encode / decode that uses it (second_stream)
     if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
@@ -1238,6 +1245,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     // k_frame_serial stages a frame's block sums, vectors and states in dynamic LDS: 15 bytes per macroblock
     if ((e = hipFuncSetAttribute((const void*)k_frame_serial, hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024)) != hipSuccess)
         return fail(ICSP_ERR_HIP, "hipFuncSetAttribute", e);
+    phase("events + function attributes");
 #define ALLOC(ptr, bytes) if ((e = hipMalloc((void**)&(ptr), (bytes))) != hipSuccess) return fail(ICSP_ERR_MEM_ALLOC, "hipMalloc " #ptr, e)
     ALLOC(ctx->d_frames, nf * g.fsz);
     ctx->b.frames = ctx->d_frames;
@@ -1254,6 +1262,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ALLOC(ctx->b.me_done, nf * sizeof(int));
     ALLOC(ctx->b.dcpred, nf * nmb * 6 * sizeof(int16_t));
 #undef ALLOC
+    phase("13 hipMalloc");
 #define ZERO(ptr, bytes) if ((e = hipMemsetAsync((ptr), 0, (bytes), ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipMemsetAsync " #ptr, e)
     ZERO(ctx->b.me_flag, nf * sizeof(int));            // k_me raises it, the serial kernel of the same step clears it
     ZERO(ctx->b.me_done, nf * sizeof(int));            // arrival tickets: 0 between launches
@@ -1262,6 +1271,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ZERO(ctx->b.mv, nf * nmb * 2);
     ZERO(ctx->b.imode, nf * nmb * 4);
 #undef ZERO
+    phase("6 hipMemsetAsync (enqueue)");
     {   // the search tables are the same for every context: once per device and process (the call costs 7-12 ms)
         static std::mutex m;
         static bool loaded[64] = {};
@@ -1274,7 +1284,9 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
             if (device_id < 64) loaded[device_id] = true;
         }
     }
+    phase("search tables + their sync");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamSynchronize", e);
+    phase("final sync");
     *out = ctx;
     return ICSP_OK;
 }
