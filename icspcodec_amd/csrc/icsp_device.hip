@@ -359,7 +359,7 @@ struct Flight { int first, n; bool used, whole, done_valid; int sidx; hipEvent_t
 struct icsp_ctx {
     icsp_params_t p;
     Geo g;
-    int device, max_frames, intra_waves, n_cu;
+    int device, slot, max_frames, intra_waves, n_cu;      // device: physical; slot: the caller's device number (per-device records)
     hipStream_t stream, stream2;      // stream2: I-frame chroma beside the luma wavefront kernel (all-intra); all I-frame kernels (IPPP)
     hipEvent_t ev_fork, ev_join;
     hipStream_t up_stream, down_stream;   // icsp_copy_streams: the device's shared transfer streams (null: transfers on `stream`)
@@ -1051,10 +1051,21 @@ const char* icsp_strerror(int s)
 
 const char* icsp_last_error(const icsp_ctx_t* ctx) { return ctx ? ctx->err.c_str() : ""; }
 
+// Test hook: ICSP_FAKE_DEVICES=N (2..64) makes the library present N devices, device d being physical device d mod (real
+// devices), each with its OWN per-device records (search tables uploaded, shared transfer streams, transfer turns) -- so that
+// the multi-device paths of a host (one uploader thread, one stream pair, one table upload per device) run with several
+// device records on a one-GPU box.  Results never depend on it.
+static int fake_devices()
+{
+    static const int n = [] { const char* v = getenv("ICSP_FAKE_DEVICES"); const int k = v ? atoi(v) : 0; return (k >= 2 && k <= 64) ? k : 0; }();
+    return n;
+}
+
 int icsp_device_count(void)
 {
     int n = 0;
-    return (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? n : 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 0; }
+    return fake_devices() ? fake_devices() : n;
 }
 
 void* icsp_host_alloc(size_t bytes)
@@ -1081,7 +1092,7 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
     static std::mutex m;
     static hipStream_t up[64], down[64];
     std::lock_guard<std::mutex> l(m);
-    const int d = ctx->device & 63;
+    const int d = ctx->slot & 63;
     if (!up[d]) {
         // The two streams must sit on two DMA engines.  A stream keeps the engine its first copy was given, the lowest idle one
         // at that moment.  So the download stream's first copy is made while the upload stream is kept busy, and the pair is
@@ -1173,12 +1184,14 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     double tph = tnow();
     auto phase = [&](const char* what) { if (trace) { const double t = tnow(); fprintf(stderr, "[icsp_create] %-28s %8.3f ms\n", what, (t - tph) * 1e3); tph = t; } };
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return ICSP_ERR_NO_DEVICE;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= (fake_devices() ? fake_devices() : ndev)) return ICSP_ERR_NO_DEVICE;
+    const int slot_id = device_id;                     // the caller's device number: index of the per-device records
+    device_id %= ndev;                                 // the physical device (the same number unless ICSP_FAKE_DEVICES is set)
     if (hipSetDevice(device_id) != hipSuccess) return ICSP_ERR_NO_DEVICE;
     phase("device count + set device");
     icsp_ctx* ctx = new (std::nothrow) icsp_ctx();
     if (!ctx) return ICSP_ERR_MEM_ALLOC;
-    ctx->p = *p; ctx->device = device_id; ctx->max_frames = max_frames;
+    ctx->p = *p; ctx->device = device_id; ctx->slot = slot_id; ctx->max_frames = max_frames;
     ctx->keep_coef = false; ctx->profiling = false; ctx->prof_mask = 0;
     memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms)); memset(ctx->prof_n, 0, sizeof(ctx->prof_n));
     Geo& g = ctx->g;
@@ -1276,12 +1289,12 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
         static std::mutex m;
         static bool loaded[64] = {};
         std::lock_guard<std::mutex> lock(m);
-        if (device_id >= 64 || !loaded[device_id]) {
+        if (slot_id >= 64 || !loaded[slot_id]) {
             MeTables t; build_me_tables(t);
             // (on the context's stream: the plain call would make the runtime create its null stream's queue, 10 ms of set-up)
             if ((e = hipMemcpyToSymbolAsync(HIP_SYMBOL(c_me), &t, sizeof(t), 0, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess ||
                 (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipMemcpyToSymbolAsync", e);
-            if (device_id < 64) loaded[device_id] = true;
+            if (slot_id < 64) loaded[slot_id] = true;
         }
     }
     phase("search tables + their sync");
@@ -1328,7 +1341,7 @@ int copy_up(icsp_ctx* ctx, void* dst, const void* src, size_t bytes)
     hipStream_t st = ctx->stream, up = ctx->up_stream;
     if (!up) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return 0; }
     HIPCHK(hipStreamSynchronize(st));                              // whatever still reads the destination
-    std::lock_guard<std::mutex> l(g_up_turn[ctx->device & 63]);
+    std::lock_guard<std::mutex> l(g_up_turn[ctx->slot & 63]);
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, up));
     HIPCHK(hipStreamSynchronize(up));
     return 0;
@@ -1343,7 +1356,7 @@ int copy_down_begin(icsp_ctx* ctx, DownTurn& turn)
 {
     if (!ctx->down_stream) return 0;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    turn.m = &g_down_turn[ctx->device & 63];
+    turn.m = &g_down_turn[ctx->slot & 63];
     turn.m->lock();
     return 0;
 }
@@ -1376,7 +1389,7 @@ int icsp_upload_sync(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
     if (int rc = check_range(ctx, first, n)) return rc;
     if (!ctx->up_stream) return ICSP_ERR_UNCORRECT_PARAM;
     if (hipSetDevice(ctx->device) != hipSuccess) return ICSP_ERR_HIP;
-    std::lock_guard<std::mutex> l(g_up_turn[ctx->device & 63]);
+    std::lock_guard<std::mutex> l(g_up_turn[ctx->slot & 63]);
     if (hipMemcpyAsync(ctx->d_frames + (size_t)first * ctx->g.fsz, yuv, (size_t)n * ctx->g.fsz, hipMemcpyHostToDevice, ctx->up_stream) != hipSuccess ||
         hipStreamSynchronize(ctx->up_stream) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
     return ICSP_OK;
@@ -1799,7 +1812,7 @@ int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* levels, uint
             }
             bool ok;
             {
-                std::lock_guard<std::mutex> t(g_up_turn[ctx->device & 63]);
+                std::lock_guard<std::mutex> t(g_up_turn[ctx->slot & 63]);
                 ok = hipMemcpyAsync(ctx->d_frames + f0 * fsz, src, cn * fsz, hipMemcpyHostToDevice, ctx->up_stream) == hipSuccess &&
                      hipStreamSynchronize(ctx->up_stream) == hipSuccess;
             }
@@ -1847,7 +1860,7 @@ int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* levels, uint
                 if (rc) break;
             }
             {
-                std::lock_guard<std::mutex> t(g_down_turn[ctx->device & 63]);
+                std::lock_guard<std::mutex> t(g_down_turn[ctx->slot & 63]);
                 hipStream_t ds = ctx->down_stream;
                 uint8_t* st = ctx->gop_stage_out[d & 1];
                 hipError_t e = hipSuccess;
@@ -1927,7 +1940,8 @@ int icsp_device_pci_bus_id(int device, char* out, int cap)
 {
     if (!out || cap < 13) return ICSP_ERR_RANGE;
     int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { (void)hipGetLastError(); return ICSP_ERR_NO_DEVICE; }
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= (fake_devices() ? fake_devices() : ndev)) { (void)hipGetLastError(); return ICSP_ERR_NO_DEVICE; }
+    device %= ndev;
     if (hipDeviceGetPCIBusId(out, cap, device) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
     return ICSP_OK;
 }
@@ -2039,7 +2053,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     icsp_ctx* ctx = new (std::nothrow) icsp_ctx();
     if (!ctx) return ICSP_ERR_MEM_ALLOC;
     ctx->p = icsp_params_t{ 352, 288, 16, 16, 0 };
-    ctx->device = 0; ctx->max_frames = 1;
+    ctx->device = 0; ctx->slot = 0; ctx->max_frames = 1;
     memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
     memset(ctx->flight, 0, sizeof(ctx->flight));
     ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true; ctx->intra_ring = true; ctx->chroma_cap = 60;

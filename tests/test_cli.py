@@ -152,3 +152,30 @@ def test_decoder_cli_writes_reference_files(tmp_path, golden_dir, idx):
     assert m and abs(float(m.group(1)) - case["psnr"]) < 1.5e-4 and (int(m.group(2)), int(m.group(3)), int(m.group(4))) == (qp, qp, period)
     r = subprocess.run([DEC, str(n), "nope.bin", "1", "1", "1", fn], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert r.returncode == 255 and r.stdout.startswith(b"fail to load output")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("period,extra", [(10, ["--gpus", "2", "--chunk", "30", "--streams", "2"]), (0, ["--gpus", "2", "--chunk", "25", "--streams", "2"]),
+                                          (10, ["--gpus", "3", "--chunk", "20"]), (10, ["--gpus", "2", "--chunk", "30", "--staged"])])
+def test_cli_two_device_records_on_one_gpu(tmp_path, golden_dir, period, extra):
+    """ICSP_FAKE_DEVICES=N: the library presents N devices (all the one GPU of this box) with per-device records of their own, so
+    icsp_enc --gpus N runs its per-device machinery -- chunk c on device c mod N, one uploader thread and one pair of shared
+    transfer streams per device, the search tables uploaded per device -- with several device records: the same files as the
+    reference's single run, and the statistics say how many devices were used.  (The closest a one-GPU box gets to --gpus 2;
+    nothing here has run on two physical devices.)"""
+    n, qp = 300, 16 if period == 0 else 8
+    name = "foremanlike" if period == 0 else "stefanlike"
+    clip = clipgen.synth_clip(name, n)
+    fn = clipgen.file_name(name, n)
+    clip.tofile(tmp_path / fn)
+    ndev = int(extra[1])
+    env = dict(os.environ, ICSP_FAKE_DEVICES=str(ndev))
+    r = subprocess.run([ENC, "-i", fn, "-n", str(n), "-q", str(qp), "--intraPeriod", str(period), "--stats"] + extra, cwd=tmp_path, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=180)
+    assert r.returncode == 0, r.stdout[-2000:]
+    st = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("[icsp_enc]")][0][len("[icsp_enc]"):])
+    assert st["devices"] == ndev and st["workers"] >= ndev and st["chunks"] >= 2 * ndev
+    streams = json.load(open(os.path.join(golden_dir, "streams.json")))
+    ref = [s for s in streams if (s["clip"], s["nframes"], s["qp"], s["intra_period"]) == (name, n, qp, period) and "bin_sha256" in s][0]
+    assert hashlib.sha256((tmp_path / f"{name}_compCIF_{qp}_{qp}_{period}.bin").read_bytes()).hexdigest() == ref["bin_sha256"]
+    assert hashlib.sha256((tmp_path / "test_yuv.yuv").read_bytes()).hexdigest() == ref["recon_sha256"]

@@ -69,3 +69,30 @@ def test_gpus_flag_spawns_the_ranks_itself():
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2
     assert d["config4"]["scaling"] == "strong" and d["config4"]["frames"] == 3390 and d["config4"]["recon_equals_reference"]
     assert d["config5"]["scaling"] == "strong" and d["config5"]["frames"] == 3000 and d["config5"]["recon_equals_oracle"]
+
+
+def test_eight_ranks_on_one_gpu_the_drivers_scaling_shape():
+    """The shape of the driver's 8-GPU run -- eight ranks, the strong-scaling legs sharded 8 ways (339 GOPs -> 43/42 per rank,
+    100 GOPs of 1088p -> 13/12 per rank) -- with all eight ranks on the one GPU of this box (gloo for the control traffic): memory
+    of eight contexts per leg, wall time well inside the driver's limit, every rank seen, every rank's regime in the line.  Not a
+    scaling measurement (the ranks share a device); no scaling curve over GPUs has been measured on hardware."""
+    import time
+    env = dict(os.environ, ICSP_BENCH_BACKEND="gloo", ICSP_BENCH_FORCE_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--repeats", "2",
+                        "--legs", "ippp,config4,config5"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1700)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    d = _last_json(r.stdout)
+    assert wall < 1500, wall
+    assert d["n_gpus"] == 8 and d["ranks_seen"] == 8 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert abs(d["value"] - 8 * 300 / (d["ms_per_step"] * 1e-3)) / d["value"] < 0.01
+    assert d["ippp"]["value"] > 1e4
+    c4, c5 = d["config4"], d["config5"]
+    assert c4["scaling"] == "strong" and c4["frames"] == 3390 and c4["recon_equals_reference"] and c4["regime"]["gops_per_rank"] in (42, 43)
+    assert c5["scaling"] == "strong" and c5["frames"] == 3000 and c5["recon_equals_oracle"] and c5["regime"]["gops_per_rank"] in (12, 13)
+    for leg in (d, d["ippp"], c4, c5, c4["all_intra_loaded"]):
+        assert "intra_lanes_per_block" in leg["regime"] and "gop_groups" in leg["regime"]
+    assert all(d["parity"].values())
