@@ -545,7 +545,7 @@ int intra_waves_chained(const Geo& g, int gc)
     return (widest + 7) / 8;
 }
 
-void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma = false);
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma = false, bool beside_p_steps = false);
 
 // Orders `stream` after everything queued on the context's other streams (chroma stream, GOP-group streams): called by whatever
 // reads results, uploads, decodes, or encodes a range that partly overlaps one in flight.  No range is "in flight" afterwards.
@@ -663,7 +663,9 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     const bool whole = !single && lazy && ctx->whole_ok && ctx->last_n > 0 && (first >= ctx->last_first + ctx->last_n || ctx->last_first >= first + n);
     ctx->last_first = first; ctx->last_n = n;
     int NG = ctx->p_groups;
-    if (NG > G / 4) NG = G / 4;                        // keep every group's launches wide enough to be worth splitting
+    // keep every group's launches wide enough to be worth splitting: a dozen GOPs per group (tools/sweep_regimes.py, one CIF range
+    // encoded again and again: 10 GOPs 0.358 M frames/s in one group against 0.341 M in two, 20 GOPs 0.679 / 0.656, 25 GOPs 0.762 / 0.812)
+    if (NG > G / 12) NG = G / 12;
     if (NG < 1 || L == 1 || whole || single) NG = 1;
     auto group_lo = [&](int k) { return (int)((long long)G * k / NG); };
     // Which ranges are in flight decides the ordering against earlier calls (flight_admit): the same range again, or a range
@@ -758,11 +760,14 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // A range placed whole on one chain stream: its I frames' chroma kernels go in front of the chain instead of in front
         // of the luma kernel -- stream2 sets the pace of the alternating regime (the ranges' luma wavefront kernels, 0.22 ms of
         // latency each, follow each other there), and the chain stream has slack (ICSP_I_CHROMA_ON_CHAIN=0: as before).
-        hipStream_t scs = (whole && ctx->chroma_on_chain) ? chain_stream(0) : s2;
+        // (Up to about 32 GOPs per range: two ranges of 30 GOPs alternating 1.246 M frames/s against 1.135 M; with 35 and 40 GOPs the
+        //  chain is the longer path and the chroma kernels are better off beside the luma kernel again: 1.209 / 1.243 M, 1.303 / 1.337 M,
+        //  three ranges in rotation 1.266 / 1.330 M; from 60 GOPs on it makes no difference -- tools/sweep_regimes.py.)
+        hipStream_t scs = (whole && ctx->chroma_on_chain && G <= 32) ? chain_stream(0) : s2;
         LT(ctx, ICSP_K_CHROMA_DC, scs, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, scs, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
         LT(ctx, ICSP_K_RESIDUAL, scs, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, scs, g, fs, b, 0, cwgs, sc_); });
-        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2); });
+        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2, false, true); });
         if (!single) {
             HIPQ(hipEventRecord(ctx->ev_join, s2));
             for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(chain_stream(k), ctx->ev_join, 0));
@@ -891,7 +896,8 @@ template <int NW> void launch_intra8_g4(const Geo& g, const FrameSel& fs, const 
 
 // G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
 // light_chroma: the chroma launches beside this one are encode_range's one-workgroup-per-CU form
-void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma)
+// beside_p_steps: the I step of an IPPP range -- P-step kernels of other GOP groups / ranges share the chip with this launch
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma, bool beside_p_steps)
 {
     // 32-lane form: two blocks per wave.  `need` waves cover the widest wavefront step in one round.
     // With at most one I frame per CU the kernel is pure latency: use `need` waves.  With more frames than CUs, cap at 8
@@ -907,7 +913,10 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     int form = ctx->force_intra_form;
     // (beside the one-workgroup-per-CU chroma launch of a range placed whole the 8-lane form wins earlier, from 1.75 frames per CU:
     //  two batches of 220 / 230 / 240 / 250 frames 1.38 / 1.44 / 1.51 / 1.58 M frames/s against 1.37 / 1.40 / 1.43 / 1.44 M)
-    if (!form) form = (20 * G_all > (light_chroma ? 35 : 42) * ctx->n_cu || need > 16) ? 8 : 32;
+    // (the I frames of an IPPP batch run beside P-step kernels that keep the chip's issue slots busy, and the 8-lane form's fewer
+    //  instructions and whole-run reconstruction stores -- 1.13 x the algorithmic bytes against 1.5 x -- win from about 1.2 frames per
+    //  CU: the twelve clips' 339 GOPs 1.594 -> 1.631 M frames/s, 100 GOPs level, 60 GOPs 1.300 -> 1.254 M: tools/sweep_regimes.py)
+    if (!form) form = (20 * G_all > (beside_p_steps ? 24 : light_chroma ? 35 : 42) * ctx->n_cu || need > 16) ? 8 : 32;
     ctx->last_rowgroup = 0;
     // rows chained in fours (k_intra_luma8<.., 4>): three quarters of the wavefront's steps for frames whose widest step fits a
     // workgroup of at most eight waves

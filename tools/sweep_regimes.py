@@ -81,9 +81,14 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--budget-s", type=float, default=0.12)
     ap.add_argument("--geoms", default=",".join(GEOMS))
+    ap.add_argument("--regimes", default="", help="only these: geometry:batch:period:ranges,...")
     a = ap.parse_args()
     regimes = []
-    if a.quick:
+    if a.regimes:
+        for x in a.regimes.split(","):
+            g, b, per, r = x.split(":")
+            regimes.append((g, int(b), int(per), int(r)))
+    elif a.quick:
         regimes = [("CIF", 300, 0, 2), ("CIF", 300, 10, 2), ("CIF", 3390, 0, 1)]
     else:
         for g in a.geoms.split(","):
