@@ -387,7 +387,7 @@ struct icsp_ctx {
     int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
     int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
     int force_intra_group;            // ICSP_INTRA_GROUP: 8-lane form with block rows chained in groups of 4 (4), the plain wavefront (1), or chosen (0)
-    int intra_waves_g4;               // waves of eight blocks that the widest step of the chained wavefront needs (0: geometry not supported)
+    int intra_waves_g4, intra_waves_g2;   // waves of eight blocks that the widest step of the chained wavefront needs (groups of four / two rows)
     int i_groups;                     // ICSP_I_GROUPS: parts an all-intra batch of more frames than CUs is launched in (1 or 2)
     int prio_lo;
     int p_groups, prio_hi;            // GOP groups whose P-step chains run on separate streams (created on first use: a stream costs
@@ -887,11 +887,21 @@ template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const Dev
     }
     hipLaunchKernelGGL((k_intra_luma8<NW, false, 0>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
 }
-// rows chained in groups of four (always with the ring; NW covers the widest step: one round)
-template <int NW> void launch_intra8_g4(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
+// rows chained in groups of GC (always with the ring; NW covers the widest step: one round)
+template <int NW, int GC> void launch_intra8_g(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
     const size_t lds = intra8_lds_bytes(g, 4) + (size_t)ring_slots_exact(NW) * 64 * kRingBlocks;
-    hipLaunchKernelGGL((k_intra_luma8<NW, true, 4>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+    hipLaunchKernelGGL((k_intra_luma8<NW, true, GC>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+}
+template <int GC> void launch_intra8_chained(int nw, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
+{
+    if (nw <= 1)       launch_intra8_g<1, GC>(g, fs, b, G, st);
+    else if (nw <= 2)  launch_intra8_g<2, GC>(g, fs, b, G, st);
+    else if (nw <= 3)  launch_intra8_g<3, GC>(g, fs, b, G, st);
+    else if (nw <= 4)  launch_intra8_g<4, GC>(g, fs, b, G, st);
+    else if (nw <= 5)  launch_intra8_g<5, GC>(g, fs, b, G, st);
+    else if (nw <= 6)  launch_intra8_g<6, GC>(g, fs, b, G, st);
+    else               launch_intra8_g<8, GC>(g, fs, b, G, st);
 }
 
 // G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
@@ -916,23 +926,31 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     // (the I frames of an IPPP batch run beside P-step kernels that keep the chip's issue slots busy, and the 8-lane form's fewer
     //  instructions and whole-run reconstruction stores -- 1.13 x the algorithmic bytes against 1.5 x -- win from about 1.2 frames per
     //  CU: the twelve clips' 339 GOPs 1.594 -> 1.631 M frames/s, 100 GOPs level, 60 GOPs 1.300 -> 1.254 M: tools/sweep_regimes.py)
-    if (!form) form = (20 * G_all > (beside_p_steps ? 24 : light_chroma ? 35 : 42) * ctx->n_cu || need > 16) ? 8 : 32;
+    // Frames wider than one round of the 32-lane form (4CIF: 22 waves' worth, 1088p: 60) and frames much taller than wide (352x576:
+    // 186 wavefront steps of at most 22 blocks) leave the latency form as soon as frames share CUs; while every frame has a CU of
+    // its own the 32-lane form wins on them too, in several rounds per step if need be (tools/sweep_regimes.py, profiles/r04_sweep.json:
+    // 4CIF, two alternating ranges of 25 ... 100 frames 0.070 -> 0.083 ... 0.271 -> 0.311 M frames/s against the 8-lane form the width
+    // rule used to force; 352x576, two ranges of 175 frames 0.617 (32-lane, two per CU) / 0.667 (8-lane) / 0.710 (rows chained)).
+    // (Beyond two rounds per step -- 720p: 40 waves' worth, 1088p: 60 -- the 32-lane form loses at every batch size, 15-28 %:
+    //  those frames stay with the 8-lane form whatever the load, as before.)
+    const bool wide = need > 16, tall = g.rows8 * 2 >= g.cols8 * 3;
+    if (!form) form = wide ? ((need <= 24 && G_all <= ctx->n_cu) ? 32 : 8)
+                    : tall ? (G_all > ctx->n_cu ? 8 : 32)
+                           : (20 * G_all > (beside_p_steps ? 24 : light_chroma ? 35 : 42) * ctx->n_cu ? 8 : 32);
     ctx->last_rowgroup = 0;
     // rows chained in fours (k_intra_luma8<.., 4>): three quarters of the wavefront's steps for frames whose widest step fits a
     // workgroup of at most eight waves
-    const int nw4 = ctx->intra_waves_g4;
-    bool g4 = ctx->force_intra_group == 4;
-    if (g4 && (nw4 < 1 || nw4 > 8 || !ctx->intra_ring || (ctx->force_intra_nw && ctx->force_intra_nw < nw4) || ctx->force_intra_form == 32)) g4 = false;
-    if (g4) {
-        const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : nw4;
-        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_ring = true; ctx->last_rowgroup = 4;
-        if (nw <= 1)       launch_intra8_g4<1>(g, fs, b, G, st);
-        else if (nw <= 2)  launch_intra8_g4<2>(g, fs, b, G, st);
-        else if (nw <= 3)  launch_intra8_g4<3>(g, fs, b, G, st);
-        else if (nw <= 4)  launch_intra8_g4<4>(g, fs, b, G, st);
-        else if (nw <= 5)  launch_intra8_g4<5>(g, fs, b, G, st);
-        else if (nw <= 6)  launch_intra8_g4<6>(g, fs, b, G, st);
-        else               launch_intra8_g4<8>(g, fs, b, G, st);
+    // chosen by itself only where it was measured to win by more than noise: tall frames with one to 2.4 frames per CU in flight
+    // (352x576: +5-15 % over the plain 8-lane wavefront there; CIF: one 270-400-frame range encoded again and again +0.5-2.5 %, not taken)
+    const bool auto4 = !ctx->force_intra_group && !ctx->force_intra_form && form == 8 && tall && !beside_p_steps && 20 * G_all <= 48 * ctx->n_cu;
+    const int gc = (ctx->force_intra_group == 4 || auto4) ? 4 : ctx->force_intra_group == 2 ? 2 : 0;
+    const int nwc = gc == 4 ? ctx->intra_waves_g4 : gc == 2 ? ctx->intra_waves_g2 : 0;
+    bool chained = gc != 0;
+    if (chained && (nwc < 1 || nwc > 8 || !ctx->intra_ring || (ctx->force_intra_nw && ctx->force_intra_nw < nwc) || ctx->force_intra_form == 32)) chained = false;
+    if (chained) {
+        const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : nwc;
+        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_ring = true; ctx->last_rowgroup = gc;
+        if (gc == 4) launch_intra8_chained<4>(nw, g, fs, b, G, st); else launch_intra8_chained<2>(nw, g, fs, b, G, st);
         return;
     }
     if (form == 8) {
@@ -1216,7 +1234,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     g.mtpr = (uint32_t)(0x100000000ull / (unsigned)((g.sw + 1) / 2) + 1);
     g.fsz = (long long)g.W * g.H * 3 / 2;
     ctx->intra_waves = intra_waves_needed(g);
-    ctx->intra_waves_g4 = intra_waves_chained(g, 4);
+    ctx->intra_waves_g4 = intra_waves_chained(g, 4); ctx->intra_waves_g2 = intra_waves_chained(g, 2);
     ctx->n_cu = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ctx->n_cu = v; }
     memset(&ctx->b, 0, sizeof(ctx->b));
@@ -1243,7 +1261,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) || !env_int("ICSP_I_GROUPS", 1, 2, &ctx->i_groups) ||
         !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
         (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32) ||
-        !env_int("ICSP_INTRA_GROUP", 0, 4, &ctx->force_intra_group) || (ctx->force_intra_group != 0 && ctx->force_intra_group != 1 && ctx->force_intra_group != 4) ||
+        !env_int("ICSP_INTRA_GROUP", 0, 4, &ctx->force_intra_group) || (ctx->force_intra_group != 0 && ctx->force_intra_group != 1 && ctx->force_intra_group != 2 && ctx->force_intra_group != 4) ||
         !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices) ||
         !env_int("ICSP_SERIAL_PRIO", 0, 1, &g.prio) || !env_int("ICSP_SERIAL_BANDS", 0, 1, &g.bands)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     ctx->no_fuse = no_fuse != 0;
@@ -2071,7 +2089,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
     ctx->gop_stage_in[0] = ctx->gop_stage_in[1] = ctx->gop_stage_out[0] = ctx->gop_stage_out[1] = nullptr;
     ctx->gop_stage_in_cap = ctx->gop_stage_out_cap = 0; memset(ctx->gop_ev, 0, sizeof(ctx->gop_ev)); ctx->gop_pool = nullptr;
-    ctx->force_intra_group = 0; ctx->intra_waves_g4 = 0; ctx->last_rowgroup = 0;
+    ctx->force_intra_group = 0; ctx->intra_waves_g4 = ctx->intra_waves_g2 = 0; ctx->last_rowgroup = 0;
     ctx->s2_dirty = ctx->st_ahead = ctx->always_sync = ctx->p_dirty = false;
     ctx->keep_coef = ctx->profiling = false; ctx->prof_mask = 0;
     poison(ctx, "icsp_debug_poisoned_context", hipErrorUnknown);

@@ -85,6 +85,23 @@ def test_rows_chained_in_fours_matches_oracle(rows4, name, n, qdc, qac, period, 
     assert np.array_equal(mode[0], dbg["mode"])
 
 
+@pytest.mark.parametrize("name,n,qdc,qac,period,w,h", [
+    ("foremanlike", 3, 16, 16, 0, 352, 288), ("mobilelike", 2, 1, 1, 0, 352, 288), ("stefanlike", 4, 8, 8, 2, 352, 288),
+    ("tablelike", 3, 8, 8, 0, 64, 48), ("newslike", 2, 16, 16, 0, 32, 16), ("mobilelike", 2, 3, 255, 0, 720, 480),
+    ("mobilelike", 2, 16, 16, 2, 32, 2304), ("tablelike", 2, 8, 8, 0, 4096, 32), ("mobilelike", 2, 2, 5, 0, 176, 144),
+])
+def test_rows_chained_in_pairs_matches_oracle(monkeypatch, name, n, qdc, qac, period, w, h):
+    """ICSP_INTRA_GROUP=2: block rows chained in pairs (96 steps per CIF frame, four waves)."""
+    monkeypatch.setenv("ICSP_INTRA_GROUP", "2")
+    clip = clipgen.synth_clip(name, n, width=w, height=h)
+    enc = capi.Encoder(w, h, qdc, qac, period, max_frames=n)
+    got = enc.encode(clip)
+    ch = enc.last_choice()
+    enc.close()
+    assert (ch["intra_lanes_per_block"], ch["intra_rows_chained"], ch["intra_recon_ring"]) == (8, 2, True)
+    _cmp(got, po.encode_sequence(clip, w, h, qdc, qac, period, nthreads=NT), f"{name} {w}x{h} n={n} q={qdc}/{qac} p={period}: ")
+
+
 @pytest.mark.parametrize("w,h", [(704, 576), (1920, 1088)])
 def test_rows_chained_falls_back_where_a_step_does_not_fit_eight_waves(rows4, w, h):
     clip = clipgen.synth_clip("mobilelike", 2, width=w, height=h)
@@ -221,7 +238,7 @@ def test_all_intra_batch_in_two_parts_back_to_back(parts):
 
 
 @pytest.mark.parametrize("var,val", [("ICSP_I_GROUPS", "3"), ("ICSP_P_GROUPS", "0"), ("ICSP_NO_FUSE", "yes"), ("ICSP_INTRA_FORM", "16"),
-                                     ("ICSP_INTRA_NW", "17"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_XCD_SLICES", "-1"), ("ICSP_I_GROUPS", ""), ("ICSP_INTRA_RING", "2"), ("ICSP_CHROMA_CAP", "121")])
+                                     ("ICSP_INTRA_NW", "17"), ("ICSP_INTRA_GROUP", "3"), ("ICSP_XCD_SLICES", "-1"), ("ICSP_I_GROUPS", ""), ("ICSP_INTRA_RING", "2"), ("ICSP_CHROMA_CAP", "121")])
 def test_override_outside_its_range_fails_the_create(var, val):
     """include/icsp_hip.h: a tuning override that is not a whole number in its range makes icsp_create fail."""
     os.environ[var] = val

@@ -123,6 +123,9 @@ def main():
                "default_choice": choice, "forced_fps": {k: round(v, 1) for k, v in forced.items()}, "best_forced": best_k,
                "default_over_best": round(dflt / best, 4)}
         rows.append(row)
+        if a.out:                                                       # (after every regime: a run cut short keeps what it has)
+            json.dump({"tool": "tools/sweep_regimes.py", "budget_s_per_measurement": a.budget_s, "regimes": len(rows), "partial": True,
+                       "wall_s": round(time.time() - t_all, 1), "rows": rows}, open(a.out, "w"), indent=1)
         print(f"{g:8s} b={b:5d} n={n:5d} p={period:2d} R={r}: default {dflt:10.0f}  best forced {best_k:24s} {forced[best_k]:10.0f}  ratio {dflt / best:.3f}", flush=True)
     below = [r for r in rows if r["default_over_best"] < 0.97]
     out = {"tool": "tools/sweep_regimes.py", "budget_s_per_measurement": a.budget_s, "regimes": len(rows), "wall_s": round(time.time() - t_all, 1),
