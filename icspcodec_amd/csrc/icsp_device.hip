@@ -694,7 +694,10 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // long as its slowest workgroup.  Two launches on two streams (unequal parts, so that they do not fall into step), each
         // following only what its own stream carries, keep the early finishers busy: a part starts as soon as the part before
         // it on its stream is through (300 CIF frames: 0.94 M -> 1.04 M frames/s; 600: +1 %).
-        const int NGI = (G > ctx->n_cu && !whole && !single) ? ctx->i_groups : 1;
+        // (not where the rows-chained form will be chosen -- tall frames, up to 2.4 frames per CU: 352x576, 500 frames 0.800 M frames/s
+        //  in two parts against 0.845 M in one)
+        const bool chained_band = g.rows8 * 2 >= g.cols8 * 3 && 20 * G >= 30 * ctx->n_cu && 20 * G <= 48 * ctx->n_cu && !ctx->force_intra_form && !ctx->force_intra_group;
+        const int NGI = (G > ctx->n_cu && !whole && !single && !chained_band) ? ctx->i_groups : 1;
         // the chroma launch may take the one-workgroup-per-CU form (below): frames whose luma workgroups have at most three waves
         // (the room left on a CU was measured for those), and as long as a CU's share of the chroma units, at 4.5 us each, stays
         // within 0.85 of the luma step (1.67 us per wavefront step with two batches in flight) -- CIF: up to 367 frames
@@ -926,23 +929,26 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     // (the I frames of an IPPP batch run beside P-step kernels that keep the chip's issue slots busy, and the 8-lane form's fewer
     //  instructions and whole-run reconstruction stores -- 1.13 x the algorithmic bytes against 1.5 x -- win from about 1.2 frames per
     //  CU: the twelve clips' 339 GOPs 1.594 -> 1.631 M frames/s, 100 GOPs level, 60 GOPs 1.300 -> 1.254 M: tools/sweep_regimes.py)
-    // Frames wider than one round of the 32-lane form (4CIF: 22 waves' worth, 1088p: 60) and frames much taller than wide (352x576:
-    // 186 wavefront steps of at most 22 blocks) leave the latency form as soon as frames share CUs; while every frame has a CU of
-    // its own the 32-lane form wins on them too, in several rounds per step if need be (tools/sweep_regimes.py, profiles/r04_sweep.json:
-    // 4CIF, two alternating ranges of 25 ... 100 frames 0.070 -> 0.083 ... 0.271 -> 0.311 M frames/s against the 8-lane form the width
-    // rule used to force; 352x576, two ranges of 175 frames 0.617 (32-lane, two per CU) / 0.667 (8-lane) / 0.710 (rows chained)).
-    // (Beyond two rounds per step -- 720p: 40 waves' worth, 1088p: 60 -- the 32-lane form loses at every batch size, 15-28 %:
-    //  those frames stay with the 8-lane form whatever the load, as before.)
+    // By geometry class (tools/sweep_regimes.py, profiles/r04_sweep.json; f = frames in flight per CU, M frames/s 32-lane / 8-lane):
+    //   CIF-class (at most 16 waves' worth per step, not taller than 1.5 x its width): the thresholds above;
+    //   4CIF-class (17-24 waves' worth: two rounds of the 32-lane form): 32-lane up to f = 0.8 -- two alternating ranges of 25 ... 100
+    //     frames 0.083 / 0.070 ... 0.311 / 0.271, one range of 150 frames 0.246 / 0.239, of 250 frames 0.329 / 0.360; beside P steps up
+    //     to f = 0.2 (25 I frames 0.289 / 0.272, 84 I frames 0.362 / 0.385);
+    //   wider still (720p: 40 waves' worth, 1088p: 60): the 32-lane form loses 15-28 % at every batch size -- always 8-lane;
+    //   tall frames (352x576: 186 wavefront steps of at most 22 blocks): 32-lane while every frame has a CU of its own (f <= 1; beside P
+    //     steps f <= 0.5), then the 8-lane form with its rows chained in fours (below) -- two ranges of 175 frames 0.617 / 0.667 / 0.710.
     const bool wide = need > 16, tall = g.rows8 * 2 >= g.cols8 * 3;
-    if (!form) form = wide ? ((need <= 24 && G_all <= ctx->n_cu) ? 32 : 8)
-                    : tall ? (G_all > ctx->n_cu ? 8 : 32)
+    if (!form) form = wide ? ((need <= 24 && (beside_p_steps ? 5 * G_all <= ctx->n_cu : 5 * G_all <= 4 * ctx->n_cu)) ? 32 : 8)
+                    : tall ? ((beside_p_steps ? 2 * G_all : G_all) > ctx->n_cu ? 8 : 32)
                            : (20 * G_all > (beside_p_steps ? 24 : light_chroma ? 35 : 42) * ctx->n_cu ? 8 : 32);
     ctx->last_rowgroup = 0;
-    // rows chained in fours (k_intra_luma8<.., 4>): three quarters of the wavefront's steps for frames whose widest step fits a
-    // workgroup of at most eight waves
-    // chosen by itself only where it was measured to win by more than noise: tall frames with one to 2.4 frames per CU in flight
-    // (352x576: +5-15 % over the plain 8-lane wavefront there; CIF: one 270-400-frame range encoded again and again +0.5-2.5 %, not taken)
-    const bool auto4 = !ctx->force_intra_group && !ctx->force_intra_form && form == 8 && tall && !beside_p_steps && 20 * G_all <= 48 * ctx->n_cu;
+    // Rows chained in fours (k_intra_luma8<.., 4>: three quarters of the wavefront's steps, five waves instead of three) is chosen by
+    // itself only where it was measured to win by more than noise: tall frames with one to 2.4 frames per CU in flight (352x576:
+    // +5-15 % over the plain 8-lane wavefront; a range placed whole only up to 1.45 -- beside the other range's one-per-CU chroma
+    // launch three 33 KB workgroups no longer fit a CU: two ranges of 200 frames 0.698 against 0.764).  CIF: one 270-400-frame
+    // range encoded again and again +0.5-2.5 %, not taken.
+    const bool auto4 = !ctx->force_intra_group && !ctx->force_intra_form && form == 8 && tall && !beside_p_steps &&
+                       20 * G_all <= (light_chroma ? 29 : 48) * ctx->n_cu;
     const int gc = (ctx->force_intra_group == 4 || auto4) ? 4 : ctx->force_intra_group == 2 ? 2 : 0;
     const int nwc = gc == 4 ? ctx->intra_waves_g4 : gc == 2 ? ctx->intra_waves_g2 : 0;
     bool chained = gc != 0;
