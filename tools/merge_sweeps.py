@@ -5,7 +5,10 @@ out, ins = sys.argv[1], sys.argv[2:]
 rows, wall, budget = [], 0.0, None
 for p in ins:
     d = json.load(open(p))
-    rows += d["rows"]; wall += d.get("wall_s", 0); budget = d.get("budget_s_per_measurement", budget)
+    for r in d["rows"]:                                    # a later file's measurement of a regime replaces an earlier one
+        key = (r["geometry"], r["batch_cif_equivalent"], r["period"], r["ranges"])
+        rows = [x for x in rows if (x["geometry"], x["batch_cif_equivalent"], x["period"], x["ranges"]) != key] + [r]
+    wall += d.get("wall_s", 0); budget = d.get("budget_s_per_measurement", budget)
 below = [r for r in rows if r["default_over_best"] < 0.97]
 by_geo = {}
 for r in rows:
