@@ -1133,6 +1133,10 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
         // here: 0.18 ms against 0.31 ms for 8 MB each way); if not, the download stream is made anew.  (Even so about one
         // icsp_enc process in thirty still ends up with all its transfers taking turns, 18 ms instead of 13.6 for 3000 frames;
         // one in thirteen before uploads and downloads were made one at a time per stream.)
+        const bool trace = getenv("ICSP_TRACE_CREATE") != nullptr;
+        auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double tph = tnow();
+        auto phase = [&](const char* what) { if (trace) { const double t = tnow(); fprintf(stderr, "[icsp_copy_streams] %-26s %8.3f ms\n", what, (t - tph) * 1e3); tph = t; } };
         hipStream_t a = nullptr, b = nullptr;
         uint8_t* h = nullptr;
         const size_t nb = (size_t)8 << 20;
@@ -1143,14 +1147,19 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
                                   if (!keep) { if (*a) (void)hipStreamDestroy(*a); if (*b) (void)hipStreamDestroy(*b); }
                                   (void)hipGetLastError(); } } probe{ &a, &b, &h, &dv, false };
         HIPCHK(hipStreamCreateWithFlags(&a, hipStreamNonBlocking));
+        phase("upload stream");
         if (hipHostMalloc((void**)&h, 2 * nb, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); h = nullptr; }
+        phase("hipHostMalloc 16 MB");
         if (h && hipMalloc((void**)&dv, 2 * nb) != hipSuccess) { (void)hipGetLastError(); dv = nullptr; (void)hipHostFree(h); h = nullptr; }
-        if (dv) (void)hipMemset(dv, 0, 2 * nb);
+        // (on the new stream: a plain hipMemset would make the runtime create its null stream's queue first)
+        if (dv) { (void)hipMemsetAsync(dv, 0, 2 * nb, a); (void)hipStreamSynchronize(a); }
+        phase("hipMalloc + memset");
         auto seconds = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         if (h) {
             memset(h, 0, 2 * nb);
             (void)hipMemcpyAsync(dv, h, nb, hipMemcpyHostToDevice, a);       // first use of the upload stream
             (void)hipStreamSynchronize(a);
+            phase("first upload");
         }
         for (int attempt = 0; attempt < 4; attempt++) {
             HIPCHK(hipStreamCreateWithFlags(&b, hipStreamNonBlocking));
@@ -1171,6 +1180,7 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
                 (void)hipStreamSynchronize(a); (void)hipStreamSynchronize(b);
                 t_both = std::min(t_both, seconds() - t);
             }
+            phase("download stream + timing");
             if (t_both < 0.8 * t_seq) break;
             if (attempt < 3) { (void)hipStreamDestroy(b); b = nullptr; }
         }

@@ -454,20 +454,33 @@ int main(int argc, char* argv[])
             u->cv.notify_all();
         }
     };
+    // Contexts and the devices' transfer-stream pairs are made HERE, one after the other, before any worker thread runs: a stream
+    // (a hardware queue) takes 3 ms to create on an idle device and 12-55 ms while another thread's kernels or pinning calls are
+    // in flight (every queue of the process is re-mapped; `tools/trace_copy_streams.sh`), which is what the workers' concurrent
+    // set-up used to run into (3000 frames, two workers: create + copy streams 0.09-0.28 s -> see DESIGN.md section 4d).
+    {
+        const int cmax = std::min(chunk, n);
+        std::vector<bool> pair_made(ndev, false);
+        for (auto& w : workers) {
+            double t0 = now();
+            w.rc = icsp_create(&w.ctx, &params, w.device, cmax);
+            if (!w.rc) w.rc = icsp_set_groups(w.ctx, p_groups, i_groups);
+            // one chunk in all: the clip is encoded in a few milliseconds, a second stream takes longer than that to create
+            if (!w.rc && nchunks == 1) w.rc = icsp_single_stream(w.ctx, 1);
+            w.t_create = now() - t0; t0 = now();
+            if (!w.rc && shared_copies && !pair_made[w.device]) { w.rc = icsp_copy_streams(w.ctx, 1); pair_made[w.device] = true; }
+            w.t_copystreams = now() - t0;
+        }
+    }
     auto work = [&](Worker* w) {
         double t0 = now();
         if (placement) { w->node = dev_node[w->device % ndev_used]; (void)icsp_bind_thread_to_node(w->node, &w->bound); }
         const int cmax = std::min(chunk, n);
-        w->rc = icsp_create(&w->ctx, &params, w->device, cmax);
-        if (!w->rc) w->rc = icsp_set_groups(w->ctx, p_groups, i_groups);
-        // one chunk in all: the clip is encoded in a few milliseconds, a second stream takes longer than that to create
-        if (!w->rc && nchunks == 1) w->rc = icsp_single_stream(w->ctx, 1);
-        w->t_create = now() - t0;
         double t1 = now();
         if (!w->rc) w->rc = icsp_prepare(w->ctx);
         w->t_prepare = now() - t1; t1 = now();
-        if (!w->rc && shared_copies) w->rc = icsp_copy_streams(w->ctx, 1);
-        w->t_copystreams = now() - t1; t1 = now();
+        if (!w->rc && shared_copies) w->rc = icsp_copy_streams(w->ctx, 1);          // (the device's pair exists: this only adopts it)
+        w->t_copystreams += now() - t1; t1 = now();
         if (w->rc) w->err = std::string(icsp_strerror(w->rc)) + ": " + (w->ctx ? icsp_last_error(w->ctx) : "");
         maps_settled.wait();
         w->t_mapwait = now() - t1; t1 = now();
@@ -512,7 +525,7 @@ int main(int argc, char* argv[])
                 memset(bin_map + 14, 0, (size_t)(b / 8) + 1);
         }
         w->t_warm = now() - t1;
-        w->t_setup = now() - t0;
+        w->t_setup = now() - t0 + w->t_create;
         {   // every worker arrives here, failed or not; the last arrival ends "init"
             std::unique_lock<std::mutex> l(ready.m);
             if (++ready.waiting == ready.total) { ready.t_last = now(); ready.cv.notify_all(); }
