@@ -938,9 +938,11 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     //   tall frames (352x576: 186 wavefront steps of at most 22 blocks): 32-lane while every frame has a CU of its own (f <= 1; beside P
     //     steps f <= 0.5), then the 8-lane form with its rows chained in fours (below) -- two ranges of 175 frames 0.617 / 0.667 / 0.710.
     const bool wide = need > 16, tall = g.rows8 * 2 >= g.cols8 * 3;
+    //   CIF-class, round 4: from one frame per CU on, the 8-lane form with its rows chained in PAIRS (below) beats both the 32-lane form
+    //     and the plain 8-lane wavefront -- so the latency form ends where frames start to share CUs (beside P steps, which load the chip anyway: at 0.35 frames per CU).
     if (!form) form = wide ? ((need <= 24 && (beside_p_steps ? 5 * G_all <= ctx->n_cu : 5 * G_all <= 4 * ctx->n_cu)) ? 32 : 8)
                     : tall ? ((beside_p_steps ? 2 * G_all : G_all) > ctx->n_cu ? 8 : 32)
-                           : (20 * G_all > (beside_p_steps ? 24 : light_chroma ? 35 : 42) * ctx->n_cu ? 8 : 32);
+                           : (20 * G_all > (beside_p_steps ? 7 : 20) * ctx->n_cu ? 8 : 32);
     ctx->last_rowgroup = 0;
     // Rows chained in fours (k_intra_luma8<.., 4>: three quarters of the wavefront's steps, five waves instead of three) is chosen by
     // itself only where it was measured to win by more than noise: tall frames with one to 2.4 frames per CU in flight (352x576:
@@ -949,7 +951,17 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     // range encoded again and again +0.5-2.5 %, not taken.
     const bool auto4 = !ctx->force_intra_group && !ctx->force_intra_form && form == 8 && tall && !beside_p_steps &&
                        20 * G_all <= (light_chroma ? 29 : 48) * ctx->n_cu;
-    const int gc = (ctx->force_intra_group == 4 || auto4) ? 4 : ctx->force_intra_group == 2 ? 2 : 0;
+    // Rows chained in PAIRS (k_intra_luma8<.., 2>: 96 steps per CIF frame instead of 114, FOUR waves -- one per SIMD, which the five
+    // waves of the groups of four are not -- 26 KB of LDS: six workgroups per CU) is the form of CIF-class frames from one to 5.5 frames
+    // per CU in flight (tools/ab_intra_g2.sh, M frames/s 32-lane / plain 8-lane / pairs; two alternating ranges of 150 ... 600 frames:
+    // 1.00 / 0.95 / 1.05, 1.28 / 1.25 / 1.37, 1.44 / 1.57 / 1.72, 1.41 / 1.56 / 1.71 (the headline), 1.47 / 1.70 / 1.86, 1.47 / 1.73 / 1.89,
+    // 1.47 / 1.96 / 2.03, 1.47 / 2.00 / 2.15; 800 frames 1.48 / 2.16 / 2.13: from there the plain wavefront's seven workgroups per CU win;
+    // one range again and again, 300 ... 1000 frames: 1.05 / 0.96 / 1.05, 1.30 / 1.19 / 1.33, 1.42 / 1.30 / 1.43, 1.41 / 1.52 / 1.68,
+    // 1.47 / 1.74 / 1.88, 1.44 / 1.91 / 2.01; 3390 frames 1.47 / 2.27 / 2.17).
+    // (The I step of an IPPP batch, beside P-step kernels: pairs from 0.35 frames per CU -- two ranges of 100 GOPs 1.54 -> 1.58 M frames/s,
+    //  339 GOPs 1.71 -> 1.73 M; 30 GOPs: the 32-lane form, 1.25 against 1.13 M.)
+    const bool auto2 = !ctx->force_intra_group && !ctx->force_intra_form && form == 8 && !wide && !tall && 20 * G_all <= 110 * ctx->n_cu;
+    const int gc = (ctx->force_intra_group == 4 || auto4) ? 4 : (ctx->force_intra_group == 2 || auto2) ? 2 : 0;
     const int nwc = gc == 4 ? ctx->intra_waves_g4 : gc == 2 ? ctx->intra_waves_g2 : 0;
     bool chained = gc != 0;
     if (chained && (nwc < 1 || nwc > 8 || !ctx->intra_ring || (ctx->force_intra_nw && ctx->force_intra_nw < nwc) || ctx->force_intra_form == 32)) chained = false;

@@ -2,8 +2,8 @@
 # A/B of the 8-lane intra kernel's wavefront forms on the GPU box (through gpurun, from the repo root): the plain wavefront
 # (ICSP_INTRA_GROUP=1) against rows chained in fours (4), per regime.  Usage: tools/ab_intra.sh [passes]
 P=${1:-200}
-for rep in 1 2; do
-for g in 1 4; do
+for rep in 1; do
+for g in 1 2 4; do
   echo "== ICSP_INTRA_GROUP=$g"
   ICSP_INTRA_GROUP=$g python tools/alt_ranges.py 0 16 300 2 $P
   ICSP_INTRA_GROUP=$g python tools/alt_ranges.py 0 16 300 1 $P

@@ -7,8 +7,8 @@ Regimes: geometry {CIF, 352x576, 4CIF, 720p, 1088p} x batch {100 ... 3390 CIF fr
 10} x {one resident range encoded again and again, two alternating, three in rotation}.  For each regime the resident throughput
 with everything left to the library (default) and with one knob forced at a time:
 
-    all-intra: ICSP_INTRA_FORM 8 / 32, ICSP_INTRA_GROUP 4 (rows chained), ICSP_CHROMA_CAP 0, ICSP_WHOLE 0 (two ranges or more), ICSP_I_GROUPS 1 (one range)
-    period 10: ICSP_P_GROUPS 1 / 2, ICSP_WHOLE 0 (two ranges or more), ICSP_INTRA_FORM 8 / 32 (the I step), ICSP_I_CHROMA_ON_CHAIN 0
+    all-intra: ICSP_INTRA_FORM 8 (plain wavefront) / 32, ICSP_INTRA_GROUP 2 / 4 (rows chained in pairs / fours), ICSP_CHROMA_CAP 0, ICSP_WHOLE 0 (two ranges or more), ICSP_I_GROUPS 1 (one range)
+    period 10: ICSP_P_GROUPS 1 / 2, ICSP_WHOLE 0 (two ranges or more), ICSP_INTRA_FORM 8 / 32, ICSP_INTRA_GROUP 2 (the I step), ICSP_I_CHROMA_ON_CHAIN 0
 
 Every setting produces the same bytes (tests/); this is about speed only.  Writes the table and a summary (worst default / best
 ratio, the regimes below 0.97) as JSON.  --quick: three regimes (the -m gpu smoke test)."""
@@ -25,8 +25,8 @@ from icspcodec_amd import capi, clipgen  # noqa: E402
 
 GEOMS = {"CIF": (352, 288), "352x576": (352, 576), "4CIF": (704, 576), "720p": (1280, 720), "1088p": (1920, 1088)}
 BATCHES = [100, 200, 250, 270, 300, 350, 400, 600, 1000, 3390]          # CIF frames' worth of macroblocks
-KNOBS_AI = [("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "4"), ("ICSP_CHROMA_CAP", "0"), ("ICSP_WHOLE", "0"), ("ICSP_I_GROUPS", "1")]
-KNOBS_IP = [("ICSP_P_GROUPS", "1"), ("ICSP_P_GROUPS", "2"), ("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_I_CHROMA_ON_CHAIN", "0")]
+KNOBS_AI = [("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_INTRA_GROUP", "4"), ("ICSP_CHROMA_CAP", "0"), ("ICSP_WHOLE", "0"), ("ICSP_I_GROUPS", "1")]
+KNOBS_IP = [("ICSP_P_GROUPS", "1"), ("ICSP_P_GROUPS", "2"), ("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_I_CHROMA_ON_CHAIN", "0")]
 _clips = {}
 
 
