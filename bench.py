@@ -687,11 +687,12 @@ def main():
                                  "ms_per_step is that overlap", "kernel_trace": overlap},
             "whole_frame_read_frac": round(fps / world * BYTES_I_FRAME_READ / 1e9 / HBM_PEAK_GBS, 5),
             "whole_frame_rw_frac": round(fps / world * BYTES_I_FRAME_TOTAL / 1e9 / HBM_PEAK_GBS, 5),
-            "limiter": "the contract's roofline is HBM; what binds this kernel is vector issue on a dependency chain: a CIF frame is 114 "
-                       "wavefront steps, a step is as long as its busiest SIMD needs to issue the block tasks that landed on it (one "
-                       "task: about 700 vector + 250 scalar instructions; one wave issues an instruction every 4 cycles), and with 2.3 "
-                       "frames per CU in flight the chip's issue slots are 37 % full (valu_issue_frac; 55-70 % on a loaded chip: "
-                       "config4.all_intra_loaded.issue) -- DESIGN.md section 5"}
+            "limiter": "the contract's roofline is HBM; what binds this kernel is vector issue on a dependency chain: a CIF frame is 96 "
+                       "wavefront steps (block rows chained in pairs; 114 in the plain form), a step is as long as its busiest SIMD needs to "
+                       "issue the block tasks that landed on it (one task: about 720 vector + 220 scalar instructions; one wave issues an "
+                       "instruction every 4 cycles), and with 2.3 frames per CU in flight the chip's issue slots are about 40 % full "
+                       "(valu_issue_frac; 74-84 % on the loaded legs: config4.issue, config4.all_intra_loaded.issue, config5.issue) -- "
+                       "DESIGN.md section 5"}
     if pmc and kern_ms > 0:
         # chip level, like `achieved`: the instructions of one step's launches (counters of one 300-frame launch of the same kernel
         # x launches per step) over the step's share of the timed region

@@ -694,10 +694,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // long as its slowest workgroup.  Two launches on two streams (unequal parts, so that they do not fall into step), each
         // following only what its own stream carries, keep the early finishers busy: a part starts as soon as the part before
         // it on its stream is through (300 CIF frames: 0.94 M -> 1.04 M frames/s; 600: +1 %).
-        // (not where the rows-chained form will be chosen -- tall frames, up to 2.4 frames per CU: 352x576, 500 frames 0.800 M frames/s
-        //  in two parts against 0.845 M in one)
-        const bool chained_band = g.rows8 * 2 >= g.cols8 * 3 && 20 * G >= 30 * ctx->n_cu && 20 * G <= 48 * ctx->n_cu && !ctx->force_intra_form && !ctx->force_intra_group;
-        const int NGI = (G > ctx->n_cu && !whole && !single && !chained_band) ? ctx->i_groups : 1;
+        const int NGI = (G > ctx->n_cu && !whole && !single) ? ctx->i_groups : 1;
         // the chroma launch may take the one-workgroup-per-CU form (below): frames whose luma workgroups have at most three waves
         // (the room left on a CU was measured for those), and as long as a CU's share of the chroma units, at 4.5 us each, stays
         // within 0.85 of the luma step (1.67 us per wavefront step with two batches in flight) -- CIF: up to 367 frames
@@ -912,56 +909,41 @@ template <int GC> void launch_intra8_chained(int nw, const Geo& g, const FrameSe
 // beside_p_steps: the I step of an IPPP range -- P-step kernels of other GOP groups / ranges share the chip with this launch
 void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma, bool beside_p_steps)
 {
-    // 32-lane form: two blocks per wave.  `need` waves cover the widest wavefront step in one round.
-    // With at most one I frame per CU the kernel is pure latency: use `need` waves.  With more frames than CUs, cap at 8
-    // waves x 128 VGPRs so two workgroups share a CU and every frame of the batch is in flight at once (measured on
-    // 300 CIF frames: 0.45 ms vs 0.57 ms).
-    // 8-lane form (eight blocks per wave, k_intra_luma8): fewer instructions per block, more per wave and step.  It wins
-    // when the CUs are loaded anyway -- from about 2.1 frames per CU (tools/sweep_intra.sh, CIF frames of one launch: 450 frames
-    // 1.22 M frames/s against 1.34 M for the 32-lane form, 512 frames 1.34 / 1.37 M, 600 frames 1.54 / 1.42 M, 1000 frames
-    // 1.92 / 1.46 M, 3390 frames 2.26 / 1.46 M; two 300-frame ranges in flight 1.44 / 1.43 M) -- and on frames too wide for one
-    // round of the 32-lane form.
+    // Three forms of the I-frame luma kernel, chosen by how many frames are in flight per CU (f = G_all / CUs) and by the frame's
+    // geometry class; every threshold below is a measured crossover (tools/sweep_regimes.py -> profiles/r04_sweep.json, tools/ab_intra_g2.sh;
+    // DESIGN.md section 5 has the tables):
+    //   32-lane (k_intra_luma32): two blocks per wave, `need` waves cover the widest wavefront step -- the latency form, best while every
+    //     frame has a CU of its own (with more frames than CUs, capped at 8 waves x 128 VGPRs so that two workgroups share a CU);
+    //   8-lane with the block rows chained in PAIRS (k_intra_luma8<.., 2>): 96 steps per CIF frame instead of 114, four waves -- one per
+    //     SIMD --, 26 KB of LDS: six workgroups per CU.  From where frames share CUs up to 5.5 frames per CU (CIF, two alternating ranges
+    //     of 300 frames: 1.41 M frames/s 32-lane / 1.56 M plain 8-lane / 1.71 M pairs);
+    //   8-lane plain (k_intra_luma8<.., 0>): 21.7 KB, seven workgroups per CU -- the loaded chip (3390 CIF frames 1.47 / 2.27 / 2.17 M),
+    //     and every frame whose widest pairs step does not fit eight waves (720p, 1088p: the 32-lane form loses 15-28 % there at any load).
+    // Where the latency form ends: CIF-class frames f = 1 (the I step of an IPPP batch, which runs beside P-step kernels: 0.35 -- 30 GOPs
+    // 1.25 M 32-lane against 1.13 M, 100 GOPs 1.51 against 1.54 M pairs); frames much taller than wide (352x576) the same (beside P steps
+    // 0.5); 4CIF-class frames (17-24 waves' worth per step: two rounds of the 32-lane form) f = 0.8 for a range placed whole beside another
+    // (two ranges of 100 frames 0.313 M 32-lane / 0.291 M pairs), while a launch on its own or beside P steps takes pairs at any load
+    // (100 frames 0.167 / 0.173 M; 20 I frames 27.9 / 29.1 k).  Without the pairs form (ICSP_INTRA_RING=0) the thresholds are those of
+    // rounds 2-3: 8-lane from 2.1 frames per CU, 1.75 beside the one-per-CU chroma launch, 1.2 beside P steps.
     const int need = ctx->intra_waves;
     const int need8 = (need * 2 + 7) / 8;                           // waves of eight blocks for the widest step
+    const bool wide = need > 16, wide2 = wide && need <= 24, tall = g.rows8 * 2 >= g.cols8 * 3;
+    const bool pairs_ok = ctx->intra_ring && ctx->intra_waves_g2 >= 1 && ctx->intra_waves_g2 <= 8 && !ctx->force_intra_nw;
     int form = ctx->force_intra_form;
-    // (beside the one-workgroup-per-CU chroma launch of a range placed whole the 8-lane form wins earlier, from 1.75 frames per CU:
-    //  two batches of 220 / 230 / 240 / 250 frames 1.38 / 1.44 / 1.51 / 1.58 M frames/s against 1.37 / 1.40 / 1.43 / 1.44 M)
-    // (the I frames of an IPPP batch run beside P-step kernels that keep the chip's issue slots busy, and the 8-lane form's fewer
-    //  instructions and whole-run reconstruction stores -- 1.13 x the algorithmic bytes against 1.5 x -- win from about 1.2 frames per
-    //  CU: the twelve clips' 339 GOPs 1.594 -> 1.631 M frames/s, 100 GOPs level, 60 GOPs 1.300 -> 1.254 M: tools/sweep_regimes.py)
-    // By geometry class (tools/sweep_regimes.py, profiles/r04_sweep.json; f = frames in flight per CU, M frames/s 32-lane / 8-lane):
-    //   CIF-class (at most 16 waves' worth per step, not taller than 1.5 x its width): the thresholds above;
-    //   4CIF-class (17-24 waves' worth: two rounds of the 32-lane form): 32-lane up to f = 0.8 -- two alternating ranges of 25 ... 100
-    //     frames 0.083 / 0.070 ... 0.311 / 0.271, one range of 150 frames 0.246 / 0.239, of 250 frames 0.329 / 0.360; beside P steps up
-    //     to f = 0.2 (25 I frames 0.289 / 0.272, 84 I frames 0.362 / 0.385);
-    //   wider still (720p: 40 waves' worth, 1088p: 60): the 32-lane form loses 15-28 % at every batch size -- always 8-lane;
-    //   tall frames (352x576: 186 wavefront steps of at most 22 blocks): 32-lane while every frame has a CU of its own (f <= 1; beside P
-    //     steps f <= 0.5), then the 8-lane form with its rows chained in fours (below) -- two ranges of 175 frames 0.617 / 0.667 / 0.710.
-    const bool wide = need > 16, tall = g.rows8 * 2 >= g.cols8 * 3;
-    //   CIF-class, round 4: from one frame per CU on, the 8-lane form with its rows chained in PAIRS (below) beats both the 32-lane form
-    //     and the plain 8-lane wavefront -- so the latency form ends where frames start to share CUs (beside P steps, which load the chip anyway: at 0.35 frames per CU).
-    if (!form) form = wide ? ((need <= 24 && (beside_p_steps ? 5 * G_all <= ctx->n_cu : 5 * G_all <= 4 * ctx->n_cu)) ? 32 : 8)
-                    : tall ? ((beside_p_steps ? 2 * G_all : G_all) > ctx->n_cu ? 8 : 32)
-                           : (20 * G_all > (beside_p_steps ? 7 : 20) * ctx->n_cu ? 8 : 32);
+    if (!form) {
+        int lat_end;                                                // the latency form up to lat_end / 20 frames per CU
+        if (wide && !wide2)  lat_end = 0;
+        else if (!pairs_ok)  lat_end = wide2 ? (beside_p_steps ? 4 : 16) : tall ? (beside_p_steps ? 10 : 20) : (beside_p_steps ? 24 : light_chroma ? 35 : 42);
+        else if (wide2)      lat_end = (beside_p_steps || G_all == G) ? 0 : 16;
+        else if (tall)       lat_end = beside_p_steps ? 10 : 20;
+        else                 lat_end = beside_p_steps ? 7 : 20;
+        form = 20 * G_all > lat_end * ctx->n_cu ? 8 : 32;
+    }
     ctx->last_rowgroup = 0;
-    // Rows chained in fours (k_intra_luma8<.., 4>: three quarters of the wavefront's steps, five waves instead of three) is chosen by
-    // itself only where it was measured to win by more than noise: tall frames with one to 2.4 frames per CU in flight (352x576:
-    // +5-15 % over the plain 8-lane wavefront; a range placed whole only up to 1.45 -- beside the other range's one-per-CU chroma
-    // launch three 33 KB workgroups no longer fit a CU: two ranges of 200 frames 0.698 against 0.764).  CIF: one 270-400-frame
-    // range encoded again and again +0.5-2.5 %, not taken.
-    const bool auto4 = !ctx->force_intra_group && !ctx->force_intra_form && form == 8 && tall && !beside_p_steps &&
-                       20 * G_all <= (light_chroma ? 29 : 48) * ctx->n_cu;
-    // Rows chained in PAIRS (k_intra_luma8<.., 2>: 96 steps per CIF frame instead of 114, FOUR waves -- one per SIMD, which the five
-    // waves of the groups of four are not -- 26 KB of LDS: six workgroups per CU) is the form of CIF-class frames from one to 5.5 frames
-    // per CU in flight (tools/ab_intra_g2.sh, M frames/s 32-lane / plain 8-lane / pairs; two alternating ranges of 150 ... 600 frames:
-    // 1.00 / 0.95 / 1.05, 1.28 / 1.25 / 1.37, 1.44 / 1.57 / 1.72, 1.41 / 1.56 / 1.71 (the headline), 1.47 / 1.70 / 1.86, 1.47 / 1.73 / 1.89,
-    // 1.47 / 1.96 / 2.03, 1.47 / 2.00 / 2.15; 800 frames 1.48 / 2.16 / 2.13: from there the plain wavefront's seven workgroups per CU win;
-    // one range again and again, 300 ... 1000 frames: 1.05 / 0.96 / 1.05, 1.30 / 1.19 / 1.33, 1.42 / 1.30 / 1.43, 1.41 / 1.52 / 1.68,
-    // 1.47 / 1.74 / 1.88, 1.44 / 1.91 / 2.01; 3390 frames 1.47 / 2.27 / 2.17).
-    // (The I step of an IPPP batch, beside P-step kernels: pairs from 0.35 frames per CU -- two ranges of 100 GOPs 1.54 -> 1.58 M frames/s,
-    //  339 GOPs 1.71 -> 1.73 M; 30 GOPs: the 32-lane form, 1.25 against 1.13 M.)
-    const bool auto2 = !ctx->force_intra_group && !ctx->force_intra_form && form == 8 && !wide && !tall && 20 * G_all <= 110 * ctx->n_cu;
-    const int gc = (ctx->force_intra_group == 4 || auto4) ? 4 : (ctx->force_intra_group == 2 || auto2) ? 2 : 0;
+    // rows chained: pairs by the rule above; groups of four (87 steps, five waves: +13 % for a frame alone on its CU, slower
+    // wherever frames share CUs) only when asked for
+    const bool auto2 = !ctx->force_intra_group && !ctx->force_intra_form && form == 8 && pairs_ok && 20 * G_all <= 110 * ctx->n_cu;
+    const int gc = ctx->force_intra_group == 4 ? 4 : (ctx->force_intra_group == 2 || auto2) ? 2 : 0;
     const int nwc = gc == 4 ? ctx->intra_waves_g4 : gc == 2 ? ctx->intra_waves_g2 : 0;
     bool chained = gc != 0;
     if (chained && (nwc < 1 || nwc > 8 || !ctx->intra_ring || (ctx->force_intra_nw && ctx->force_intra_nw < nwc) || ctx->force_intra_form == 32)) chained = false;

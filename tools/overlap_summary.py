@@ -4,7 +4,7 @@
     overlap_summary.py <dir with *kernel_trace.csv> <bench line (json file)> <out json>
 
 bench.py's primary leg issues, on its first encoder, SETTLE_PASSES + warmup untimed steps and then repeats x steps timed ones, one
-launch of the 8-lane luma kernel (grid 300 x 192 threads) per step; the launches of the timed regions are picked by their place
+launch of the 8-lane luma kernel (300 workgroups) per step; the launches of the timed regions are picked by their place
 in that sequence.  Per launch: start, end, queue, launches of the kernel in flight at its start; summary: medians of duration
 and start-to-start distance (= the span of a step), and the chip-level rate that follows: algorithmic bytes of a launch / span."""
 import csv, glob, json, os, sys
@@ -22,8 +22,10 @@ BYTES = 300 * (4 * P + 8 * NMB)
 rows = []
 for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        if "k_intra_luma8" in r["Kernel_Name"] and int(r.get("Grid_Size") or r["Grid_Size_X"]) == 300 * 192:
+        # the 300-workgroup launches of the 8-lane luma kernel, whatever its variant (three waves, or four with the rows in pairs)
+        if "k_intra_luma8" in r["Kernel_Name"] and int(r.get("Grid_Size") or r["Grid_Size_X"]) == 300 * int(r.get("Workgroup_Size") or r["Workgroup_Size_X"]):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")))
+            kname = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
 rows.sort()
 first = SETTLE + warmup
 sel = rows[first: first + repeats * steps]
@@ -40,7 +42,7 @@ durs = [l["dur_us"] for l in launches]
 gaps = [launches[i + 1]["start_us"] - launches[i]["start_us"] for i in range(len(launches) - 1) if (i + 1) % steps != 0]
 span = med(gaps)
 res = {"source": "rocprofv3 --kernel-trace of `bench.py --steps %d --warmup %d --repeats %d --no-cpu --legs ippp` (tools/profile_round.sh); "
-                 "launches %d..%d of k_intra_luma8<3,ring> with 57600 threads = the timed regions" % (steps, warmup, repeats, first, first + len(sel) - 1),
+                 "launches %d..%d of %s on 300 workgroups = the timed regions" % (steps, warmup, repeats, first, first + len(sel) - 1, kname),
        "launches": len(sel), "launch_duration_ms_median": round(med(durs) / 1e3, 4), "start_to_start_ms_median": round(span / 1e3, 4),
        "launches_in_flight_median": med([l["in_flight_at_start"] for l in launches]),
        "algorithmic_bytes_per_launch": BYTES,

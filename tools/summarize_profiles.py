@@ -18,6 +18,7 @@ access width, and the request-size counters TCC_EA0_RDREQ_{32B,64B,128B} give th
 """
 import collections
 import csv
+import re
 import glob
 import json
 import os
@@ -33,6 +34,9 @@ KERNELS = ("k_dec_intra_luma32", "k_dec_serial", "k_dec_blocks", "k_intra_luma32
 
 
 def short(n):
+    m = re.search(r"k_intra_luma8<(\d+), (true|false), (\d+)>", n)
+    if m:                                                   # the 8-lane luma kernel by variant: waves per workgroup, rows chained in groups of
+        return "k_intra_luma8" + (f"_w{m.group(1)}g{m.group(3)}" if m.group(3) != "0" else "")
     for k in KERNELS:
         if k in n:
             s = k.replace("<", "_").rstrip("_")
@@ -119,7 +123,7 @@ for k in keys:
     kernels[f"{kn}@{grid}"] = e
 
 # algorithmic bytes of the launches the bench line and VERDICT quote (300 CIF frames; 15 frames per P-step launch)
-ALG = {"k_intra_luma32": lambda fr: fr * (4 * P + 8 * NMB), "k_intra_luma8": lambda fr: fr * (4 * P + 8 * NMB), "k_me_false": lambda fr: fr * (3 * P + 64 * NMB),
+ALG = {"k_intra_luma32": lambda fr: fr * (4 * P + 8 * NMB), "k_intra_luma8": lambda fr: fr * (4 * P + 8 * NMB), "k_intra_luma8_w4g2": lambda fr: fr * (4 * P + 8 * NMB), "k_me_false": lambda fr: fr * (3 * P + 64 * NMB),
        "k_residual8": lambda fr: fr * (3 * P + P * 3 // 2 + 3 * P + 8 * NMB)}
 for name, e in kernels.items():
     kn, grid = name.split("@")
@@ -129,6 +133,8 @@ for name, e in kernels.items():
         frames = grid // 512 if grid >= 512 * 256 else grid // 704          # <8,4> above 256 frames, else <11,1>
     elif kn == "k_intra_luma8" and grid % 192 == 0:
         frames = grid // 192                                                 # CIF: three waves per frame
+    elif kn == "k_intra_luma8_w4g2" and grid % 256 == 0:
+        frames = grid // 256                                                 # CIF, rows in pairs: four waves per frame
     elif kn == "k_me_false":
         frames = 15                                                          # configs[2]: 30 GOPs in two groups (the grid is padded to 16 frames)
     elif kn == "k_residual8" and 900 < grid // 256 < 1400:
@@ -151,13 +157,16 @@ def sq_entry(bk, waves_expected):
             "sq_wave_coverage": round(cov, 3), "issue_stall_share_of_wave_cycles": e.get("issue_stall_share_of_wave_cycles"),
             "waiting_share_of_wave_cycles": e.get("waiting_share_of_wave_cycles"),
             "source": f"rocprofv3 --pmc SQ_INSTS_VALU_{{ADD,MUL,FMA}}_F64 on {bk}, scaled by expected waves / SQ_WAVES (profiles/traffic.json, tools/profile_round.sh)"}
-dom = "k_intra_luma8@57600"
+# (round 4: the headline's launch is the pairs variant, four waves per frame; a build that picks the plain wavefront has 57600 threads)
+dom, dom_waves = "k_intra_luma8_w4g2@76800", 300 * 4
+if dom not in kernels:
+    dom, dom_waves = "k_intra_luma8@57600", 300 * 3
 old = "k_intra_luma32@153600"
 if dom in kernels and "hbm_bytes_per_launch" in kernels[dom]:
     out["k_intra_luma_kernel"] = dom
     out["k_intra_luma_bytes_per_launch"] = kernels[dom]["hbm_bytes_per_launch"]
     out["k_intra_luma_algorithmic_bytes_per_launch"] = 300 * (4 * P + 8 * NMB)
-    out["k_intra_luma_sq"] = sq_entry(dom, 300 * 3)
+    out["k_intra_luma_sq"] = sq_entry(dom, dom_waves)
 if old in kernels and "hbm_bytes_per_launch" in kernels[old]:
     out["k_intra_luma32_bytes_per_launch"] = kernels[old]["hbm_bytes_per_launch"]
     out["k_intra_luma32_sq"] = sq_entry(old, 300 * 8)
