@@ -694,7 +694,11 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // long as its slowest workgroup.  Two launches on two streams (unequal parts, so that they do not fall into step), each
         // following only what its own stream carries, keep the early finishers busy: a part starts as soon as the part before
         // it on its stream is through (300 CIF frames: 0.94 M -> 1.04 M frames/s; 600: +1 %).
-        const int NGI = (G > ctx->n_cu && !whole && !single) ? ctx->i_groups : 1;
+        // (... unless one launch fills the CUs evenly, two workgroups each: from 1.66 to 2 frames per CU -- CIF, one range again and again,
+        //  450 / 500 / 512 frames: 1.32 / 1.43 / 1.47 M frames/s in two parts against 1.40 / 1.54 / 1.57 M in one; 400 frames 1.33 / 1.28,
+        //  560 frames 1.61 / 1.50; 352x576 the same)
+        const bool even2 = 20 * G >= 33 * ctx->n_cu && G <= 2 * ctx->n_cu;
+        const int NGI = (G > ctx->n_cu && !whole && !single && !even2) ? ctx->i_groups : 1;
         // the chroma launch may take the one-workgroup-per-CU form (below): frames whose luma workgroups have at most three waves
         // (the room left on a CU was measured for those), and as long as a CU's share of the chroma units, at 4.5 us each, stays
         // within 0.85 of the luma step (1.67 us per wavefront step with two batches in flight) -- CIF: up to 367 frames
@@ -934,7 +938,7 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
         int lat_end;                                                // the latency form up to lat_end / 20 frames per CU
         if (wide && !wide2)  lat_end = 0;
         else if (!pairs_ok)  lat_end = wide2 ? (beside_p_steps ? 4 : 16) : tall ? (beside_p_steps ? 10 : 20) : (beside_p_steps ? 24 : light_chroma ? 35 : 42);
-        else if (wide2)      lat_end = (beside_p_steps || G_all == G) ? 0 : 16;
+        else if (wide2)      lat_end = beside_p_steps ? (G_all > 12 ? 4 : 0) : G_all == G ? 0 : 16;     // (beside P steps: 13-51 I frames 32-lane +3 %, fewer or more: pairs +3 %)
         else if (tall)       lat_end = beside_p_steps ? 10 : 20;
         else                 lat_end = beside_p_steps ? 7 : 20;
         form = 20 * G_all > lat_end * ctx->n_cu ? 8 : 32;
