@@ -7,7 +7,7 @@ bench.py's primary leg issues, on its first encoder, SETTLE_PASSES + warmup unti
 launch of the 8-lane luma kernel (300 workgroups) per step; the launches of the timed regions are picked by their place
 in that sequence.  Per launch: start, end, queue, launches of the kernel in flight at its start; summary: medians of duration
 and start-to-start distance (= the span of a step), and the chip-level rate that follows: algorithmic bytes of a launch / span."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 src, bench_json, out = sys.argv[1], sys.argv[2], sys.argv[3]
 line = None
 for l in open(bench_json):
@@ -25,7 +25,7 @@ for f in glob.glob(os.path.join(src, "**", "*kernel_trace.csv"), recursive=True)
         # the 300-workgroup launches of the 8-lane luma kernel, whatever its variant (three waves, or four with the rows in pairs)
         if "k_intra_luma8" in r["Kernel_Name"] and int(r.get("Grid_Size") or r["Grid_Size_X"]) == 300 * int(r.get("Workgroup_Size") or r["Workgroup_Size_X"]):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?")))
-            kname = r["Kernel_Name"].split("(anonymous namespace)::")[-1].split("(")[0]
+            kname = re.search(r"k_intra_luma8<[^>]*>", r["Kernel_Name"]).group(0)
 rows.sort()
 first = SETTLE + warmup
 sel = rows[first: first + repeats * steps]
