@@ -1,5 +1,5 @@
 #!/bin/bash
-# like cold_long.sh: mapped + pinned files against --staged, lean against pipelined; wall time, 1.5 s between runs
+# wall time of icsp_enc on a long clip (through gpurun): mapped + pinned files against --staged, each twice; 1.5 s between runs; "outside" = process start + what the kernel does after _exit
 R=$GRAFT_REPO_ROOT
 N=${1:-3000}
 T=/dev/shm/coldl_$$; mkdir -p $T; cd $T
@@ -30,10 +30,10 @@ PY
 }
 for rep in 1 2; do
 for p in 0 10; do
-one "lean mapped p=$p" --intraPeriod $p
-one "lean staged p=$p" --intraPeriod $p --staged
-one "pipelined mapped p=$p" --intraPeriod $p ICSP_ENC_PIPELINE=1
-one "pipelined staged p=$p" --intraPeriod $p --staged ICSP_ENC_PIPELINE=1
+one "mapped p=$p" --intraPeriod $p
+one "staged p=$p" --intraPeriod $p --staged
+one "mapped p=$p (again)" --intraPeriod $p
+one "staged p=$p (again)" --intraPeriod $p --staged
 done
 done
 cd /; rm -rf $T
