@@ -1746,8 +1746,11 @@ namespace {
 bool host_pinned(const void* p, size_t bytes)
 {
     if (!p || !bytes) return true;
+    // (both ends and sixteen places in between: a registration covers whole pages, so a plain buffer may start or end inside a
+    //  neighbour's registered page)
     hipPointerAttribute_t a;
-    for (const char* q : { (const char*)p, (const char*)p + bytes - 1 }) {
+    for (int k = 0; k <= 17; k++) {
+        const char* q = (const char*)p + (k == 17 ? bytes - 1 : (size_t)((unsigned __int128)(bytes - 1) * k / 17));
         memset(&a, 0, sizeof(a));
         if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }      // unknown to the runtime: pageable
         if (a.type != hipMemoryTypeHost) return false;

@@ -224,7 +224,11 @@ void icsp_host_free(void* p);
  * without write permission) or of the output file (MAP_SHARED, pages populated): icsp_upload then reads the frames and
  * icsp_download writes the reconstruction by DMA from/into the page cache, with no staging copy on the host (the reference's
  * YCbCrLoad fread, ENC:247-283, and checkResultFrames fwrite, ENC:6376-6413, become the transfers themselves).  The range is
- * usable from every device.  ICSP_ERR_HIP when the runtime refuses the range (callers fall back to staging buffers). */
+ * usable from every device.  ICSP_ERR_HIP when the runtime refuses the range (callers fall back to staging buffers).
+ * Register WHOLE PAGES that belong to the range alone (a mapping, posix_memalign(4096) with the size rounded up): a registration
+ * covers whole pages, and the runtime treats any buffer that starts inside a registered page as pinned -- an unrelated heap
+ * allocation sharing the last page of an unaligned registered one is then written by DMA as if pinned, and the device faults where
+ * the registration ends (seen in round 4 with registered numpy heap arrays; not a property of this library's transfers). */
 int icsp_host_register(void* p, size_t bytes, int read_only);
 int icsp_host_unregister(void* p);
 /* Spends a pinned range's first-use cost now: the context's stream writes `bytes` zero bytes (at most 16 MB) to it by DMA.  For
