@@ -1920,9 +1920,52 @@ int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* levels, uint
     if (uploader.joinable()) uploader.join();
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     if (need_out) unstage(nc - 1);
-    // the small arrays of the whole range, and the packed body
-    if (acflag || mpm || mvd) { if (int r2 = icsp_download(ctx, 0, n, nullptr, acflag, mpm, mvd, nullptr)) return r2; }
-    if (body) { if (int r2 = icsp_pack_bits(ctx, 0, n, body, body_cap, nbits)) return r2; }
+    // The small arrays of the whole range, and the packed body.  Plain caller memory gets these through the staging buffer too, in
+    // pieces: the call never hands the runtime a large plain pointer (which it would pin on the fly: DESIGN.md section 4e).
+    if (int r2 = join_all(ctx)) return r2;
+    auto fetch = [&](void* dst, const void* dev, size_t bytes) -> int {
+        if (!dst || !bytes) return 0;
+        DownTurn turn;
+        if (int r2 = copy_down_begin(ctx, turn)) return r2;
+        hipStream_t ds = down_of(ctx);
+        if (host_pinned(dst, bytes)) {
+            HIPCHK(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, ds));
+            return copy_down_end(ctx);
+        }
+        if (!ctx->gop_stage_out[0] || ctx->gop_stage_out_cap < ((size_t)1 << 20)) {                 // (all big results were pinned: no staging buffer yet)
+            for (int k = 0; k < 2; k++) {
+                if (ctx->gop_stage_out[k]) (void)hipHostFree(ctx->gop_stage_out[k]);
+                ctx->gop_stage_out[k] = nullptr;
+                if (hipHostMalloc((void**)&ctx->gop_stage_out[k], (size_t)4 << 20, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->gop_stage_out[k] = nullptr; ctx->gop_stage_out_cap = 0; ctx->err = "hipHostMalloc staging (out)"; return ICSP_ERR_MEM_ALLOC; }
+            }
+            ctx->gop_stage_out_cap = (size_t)4 << 20;
+        }
+        if (!ctx->gop_pool) ctx->gop_pool = new (std::nothrow) CopyPool((int)std::min(5u, hw / 2));
+        if (!ctx->gop_pool) return ICSP_ERR_MEM_ALLOC;
+        const size_t piece = ctx->gop_stage_out_cap;
+        for (size_t o = 0, k = 0; o < bytes; o += piece, k++) {                                      // transfer of piece k beside the copy of piece k - 1
+            const size_t nb = std::min(piece, bytes - o);
+            HIPCHK(hipMemcpyAsync(ctx->gop_stage_out[k & 1], (const char*)dev + o, nb, hipMemcpyDeviceToHost, ds));
+            if (k) ctx->gop_pool->copy((char*)dst + o - piece, ctx->gop_stage_out[(k - 1) & 1], piece);
+            HIPCHK(hipStreamSynchronize(ds));
+            if (o + nb >= bytes) ctx->gop_pool->copy((char*)dst + o, ctx->gop_stage_out[k & 1], nb);
+        }
+        return 0;
+    };
+    const size_t nmb6 = (size_t)n * nmb;
+    if (int r2 = fetch(acflag, ctx->b.acflag, nmb6 * 6)) return r2;
+    if (int r2 = fetch(mpm, ctx->b.mpm, nmb6 * 4)) return r2;
+    if (int r2 = fetch(mvd, ctx->b.mvd, nmb6 * 2)) return r2;
+    if (body) {
+        if (int r2 = icsp_pack_count(ctx, 0, n, nbits)) return r2;
+        const size_t nbytes = (size_t)((*nbits + 7) / 8);
+        if (nbytes > body_cap) { *nbits = 0; return ICSP_ERR_RANGE; }
+        if (nbytes) {
+            if (int r2 = pack_write(ctx, 0, n, 0)) return r2;
+            if (int r2 = fetch(body, ctx->pk.out, nbytes)) return r2;
+        }
+    }
+    if (ctx->profiling) collect_profile(ctx);
     return ICSP_OK;
 }
 } // namespace
