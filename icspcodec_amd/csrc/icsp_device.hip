@@ -923,7 +923,7 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     //     of 300 frames: 1.41 M frames/s 32-lane / 1.56 M plain 8-lane / 1.71 M pairs);
     //   8-lane plain (k_intra_luma8<.., 0>): 21.7 KB, seven workgroups per CU -- the loaded chip (3390 CIF frames 1.47 / 2.27 / 2.17 M),
     //     and every frame whose widest pairs step does not fit eight waves (720p, 1088p: the 32-lane form loses 15-28 % there at any load).
-    // Where the latency form ends: CIF-class frames f = 1 (the I step of an IPPP batch, which runs beside P-step kernels: 0.35 -- 30 GOPs
+    // Where the latency form ends: CIF-class frames f = 1 (the I step of an IPPP batch, which runs beside P-step kernels: 0.2 -- 30 GOPs
     // 1.25 M 32-lane against 1.13 M, 100 GOPs 1.51 against 1.54 M pairs); frames much taller than wide (352x576) the same (beside P steps
     // 0.5); 4CIF-class frames (17-24 waves' worth per step: two rounds of the 32-lane form) f = 0.8 for a range placed whole beside another
     // (two ranges of 100 frames 0.313 M 32-lane / 0.291 M pairs), while a launch on its own or beside P steps takes pairs at any load
@@ -940,7 +940,7 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
         else if (!pairs_ok)  lat_end = wide2 ? (beside_p_steps ? 4 : 16) : tall ? (beside_p_steps ? 10 : 20) : (beside_p_steps ? 24 : light_chroma ? 35 : 42);
         else if (wide2)      lat_end = beside_p_steps ? (G_all > 12 ? 4 : 0) : G_all == G ? 0 : 16;     // (beside P steps: 13-51 I frames 32-lane +3 %, fewer or more: pairs +3 %)
         else if (tall)       lat_end = beside_p_steps ? 10 : 20;
-        else                 lat_end = beside_p_steps ? 7 : 20;
+        else                 lat_end = beside_p_steps ? 4 : 20;   // (since the slots rotate over the waves: 60 I frames beside P steps 1.42 M 32-lane / 1.48 M pairs, 30 level)
         form = 20 * G_all > lat_end * ctx->n_cu ? 8 : 32;
     }
     ctx->last_rowgroup = 0;
