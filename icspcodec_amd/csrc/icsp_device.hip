@@ -919,10 +919,11 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     //   32-lane (k_intra_luma32): two blocks per wave, `need` waves cover the widest wavefront step -- the latency form, best while every
     //     frame has a CU of its own (with more frames than CUs, capped at 8 waves x 128 VGPRs so that two workgroups share a CU);
     //   8-lane with the block rows chained in PAIRS (k_intra_luma8<.., 2>): 96 steps per CIF frame instead of 114, four waves -- one per
-    //     SIMD --, 26 KB of LDS: six workgroups per CU.  From where frames share CUs up to 5.5 frames per CU (CIF, two alternating ranges
-    //     of 300 frames: 1.41 M frames/s 32-lane / 1.56 M plain 8-lane / 1.71 M pairs);
-    //   8-lane plain (k_intra_luma8<.., 0>): 21.7 KB, seven workgroups per CU -- the loaded chip (3390 CIF frames 1.47 / 2.27 / 2.17 M),
-    //     and every frame whose widest pairs step does not fit eight waves (720p, 1088p: the 32-lane form loses 15-28 % there at any load).
+    //     SIMD --, 26 KB of LDS: six workgroups per CU.  From where frames share CUs, at every load (CIF, two alternating ranges of 300
+    //     frames: 1.41 M frames/s 32-lane / 1.64 M plain 8-lane / 1.84 M pairs; 3390 frames 1.47 / 2.34 / 2.36 M -- with the slots of
+    //     a step rotating over the waves; before that the plain form won above 5.5 frames per CU);
+    //   8-lane plain (k_intra_luma8<.., 0>): 21.7 KB, seven workgroups per CU -- every frame whose widest pairs step does not fit
+    //     eight waves (720p, 1088p: the 32-lane form loses 15-28 % there at any load), and ICSP_INTRA_RING=0.
     // Where the latency form ends: CIF-class frames f = 1 (the I step of an IPPP batch, which runs beside P-step kernels: 0.2 -- 30 GOPs
     // 1.25 M 32-lane against 1.13 M, 100 GOPs 1.51 against 1.54 M pairs); frames much taller than wide (352x576) the same (beside P steps
     // 0.5); 4CIF-class frames (17-24 waves' worth per step: two rounds of the 32-lane form) f = 0.8 for a range placed whole beside another

@@ -31,11 +31,11 @@
  *                        frame width and the batch size)
  *   ICSP_INTRA_FORM 8|32 lanes per 8x8 block in the intra luma kernel: 32 = latency form (two blocks per wave), 8 = throughput
  *                        form (eight blocks per wave, plain wavefront); default: by frames in flight per CU and geometry class --
- *                        32 while every frame has a CU of its own, 8 with the rows in pairs (ICSP_INTRA_GROUP) up to 5.5 frames per
- *                        CU, 8 plain above and on frames too wide for pairs (profiles/r04_sweep.json)
+ *                        32 while every frame has a CU of its own, 8 with the rows in pairs (ICSP_INTRA_GROUP) above, 8 plain
+ *                        on frames too wide for pairs (profiles/r04_sweep.json)
  *   ICSP_INTRA_GROUP 0|1|2|4  8-lane intra kernel: 2 / 4 = block rows run one wavefront step apart in groups of two / four (96 / 87
  *                        steps per CIF frame instead of 114; four / five waves; frames whose widest step fits eight waves), 1 = two
- *                        steps apart throughout (plain), 0 (default) = chosen (pairs in the middle load range, see ICSP_INTRA_FORM)
+ *                        steps apart throughout (plain), 0 (default) = chosen (pairs wherever the 8-lane form is, see ICSP_INTRA_FORM)
  *   ICSP_INTRA_RING 0|1  8-lane intra kernel: reconstruction written in 32-byte runs through a ring in LDS (default 1) or as 8-byte
  *                        block rows straight from the lanes (0)
  *   ICSP_SERIAL_PRIO 0|1 1 (default): the DC-chain waves of the per-frame serial kernel run at raised issue priority
