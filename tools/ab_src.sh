@@ -2,6 +2,7 @@
 # RECORD of an experiment that was not kept ("source rows through the ring"): the build with the source rows
 # going through the reconstruction ring as the default library against the build before it as tools/lib_prev.so (every task loads
 # its own 8 bytes per row).  Neither library is in the tree any more; the script documents what was compared and how.
+cd $GRAFT_REPO_ROOT
 for lib in default lib_prev.so default lib_prev.so; do
   L=""; [ "$lib" != "default" ] && L=$GRAFT_REPO_ROOT/tools/$lib
   echo "== lib=$lib"
