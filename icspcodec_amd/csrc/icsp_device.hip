@@ -27,6 +27,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -408,6 +409,11 @@ struct icsp_ctx {
     size_t gop_stage_in_cap, gop_stage_out_cap;
     hipEvent_t gop_ev[2][2 + 3];          // per chunk in flight (two): one event per stream of the context (stream, stream2, group streams)
     struct CopyPool* gop_pool;
+    // every transfer from or into caller memory that is not KNOWN to be pinned goes through those staging buffers (xfer_up /
+    // xfer_down): the runtime never sees a plain caller pointer.  xfer_ev_*: the DMA that last used a staging buffer
+    hipEvent_t xfer_ev_in[2], xfer_ev_out[2];
+    bool xfer_in_busy[2];
+    struct CopyPool* up_pool;             // helper threads of the upload direction (icsp_upload_sync may run beside the context's own thread)
     bool keep_coef, profiling;
     unsigned prof_mask;               // which kernels get HIP events (icsp_profile_enable's argument, bit k = kernel k)
     std::vector<EvPair> ev_pending;
@@ -1055,13 +1061,140 @@ namespace {
 void gop_release(icsp_ctx* ctx)
 {
     delete ctx->gop_pool; ctx->gop_pool = nullptr;
+    delete ctx->up_pool; ctx->up_pool = nullptr;
     for (int k = 0; k < 2; k++) {
+        if (ctx->xfer_ev_in[k]) (void)hipEventDestroy(ctx->xfer_ev_in[k]);
+        if (ctx->xfer_ev_out[k]) (void)hipEventDestroy(ctx->xfer_ev_out[k]);
+        ctx->xfer_ev_in[k] = ctx->xfer_ev_out[k] = nullptr; ctx->xfer_in_busy[k] = false;
         if (ctx->gop_stage_in[k]) (void)hipHostFree(ctx->gop_stage_in[k]);
         if (ctx->gop_stage_out[k]) (void)hipHostFree(ctx->gop_stage_out[k]);
         for (auto& e : ctx->gop_ev[k]) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         ctx->gop_stage_in[k] = ctx->gop_stage_out[k] = nullptr;
     }
     ctx->gop_stage_in_cap = ctx->gop_stage_out_cap = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ transfers and caller memory
+// The runtime pins the host buffer of a large transfer from PLAIN memory on the fly and keeps such pins in a cache of its own;
+// a long-lived process that frees and re-allocates hundreds of megabytes there (glibc trims and re-maps the ranges) sooner or
+// later has a transfer routed through a pin that no longer matches the pages behind the address: "Memory access fault by GPU"
+// (round 4: about one long test session in two; tools/repro_fault.py).  So this library never hands the runtime a plain caller
+// pointer: memory it KNOWS to be pinned is the DMA source / target itself, everything else goes through two pinned staging
+// buffers per direction, filled / emptied by a few helper threads beside the transfer of the piece before.
+// Known to be pinned: ranges of icsp_host_alloc and icsp_host_register (a table of our own), and ranges for which the runtime
+// names ONE allocation that covers them whole (someone else's hipHostMalloc).  A buffer that only starts or ends inside a
+// registered page -- which the runtime's per-pointer attributes report as pinned -- is not.
+struct PinnedRanges {
+    std::mutex m;
+    std::vector<std::pair<uintptr_t, size_t>> r;
+    void add(const void* p, size_t n) { std::lock_guard<std::mutex> l(m); r.emplace_back((uintptr_t)p, n); }
+    void remove(const void* p)
+    {
+        std::lock_guard<std::mutex> l(m);
+        for (size_t k = 0; k < r.size(); k++) if (r[k].first == (uintptr_t)p) { r[k] = r.back(); r.pop_back(); return; }
+    }
+    bool covers(const void* p, size_t n)
+    {
+        std::lock_guard<std::mutex> l(m);
+        const uintptr_t a = (uintptr_t)p;
+        for (auto& e : r) if (a >= e.first && a - e.first <= e.second && n <= e.second - (a - e.first)) return true;
+        return false;
+    }
+};
+PinnedRanges& pinned_ranges() { static PinnedRanges t; return t; }
+
+bool host_pinned(const void* p, size_t bytes)
+{
+    if (!p || !bytes) return true;
+    if (pinned_ranges().covers(p, bytes)) return true;
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }      // unknown to the runtime: pageable
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const uintptr_t d = (uintptr_t)a.devicePointer, b = (uintptr_t)base;
+    return d >= b && d - b <= size && bytes <= size - (d - b);
+}
+
+constexpr size_t kXferPiece = (size_t)16 << 20;
+// both staging buffers of a direction hold at least `need` bytes (never shrinks)
+int stage_reserve(icsp_ctx* ctx, bool in, size_t need)
+{
+    uint8_t** buf = in ? ctx->gop_stage_in : ctx->gop_stage_out;
+    size_t& cap = in ? ctx->gop_stage_in_cap : ctx->gop_stage_out_cap;
+    hipEvent_t* ev = in ? ctx->xfer_ev_in : ctx->xfer_ev_out;
+    for (int k = 0; k < 2; k++) if (!ev[k]) HIPCHK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+    if (need <= cap && buf[0] && buf[1]) return 0;
+    for (int k = 0; k < 2; k++) {
+        if (in && ctx->xfer_in_busy[k]) { (void)hipEventSynchronize(ev[k]); ctx->xfer_in_busy[k] = false; }     // a DMA may still read the old buffer
+        if (buf[k]) (void)hipHostFree(buf[k]);
+        buf[k] = nullptr;
+        if (hipHostMalloc((void**)&buf[k], need, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError(); buf[k] = nullptr; cap = 0;
+            ctx->err = in ? "hipHostMalloc staging (in)" : "hipHostMalloc staging (out)";
+            return ICSP_ERR_MEM_ALLOC;
+        }
+    }
+    cap = need;
+    return 0;
+}
+CopyPool* copy_pool(CopyPool*& slot)
+{
+    if (!slot) slot = new (std::nothrow) CopyPool((int)std::min(5u, std::max(2u, std::thread::hardware_concurrency()) / 2));
+    return slot;
+}
+// before the staging buffers of the upload direction are written by anything else (icsp_encode_gop's uploader)
+void xfer_in_drain(icsp_ctx* ctx)
+{
+    for (int k = 0; k < 2; k++) if (ctx->xfer_in_busy[k]) { (void)hipEventSynchronize(ctx->xfer_ev_in[k]); ctx->xfer_in_busy[k] = false; }
+}
+
+// Host -> device on `st`.  Pinned source: one asynchronous copy.  Anything else: piece by piece through the staging pair; the call
+// returns when the last piece has been COPIED into its staging buffer -- the caller's memory is no longer read, the last DMAs may
+// still run (like the direct copy; a later use of the buffers waits for them).
+int xfer_up(icsp_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    if (!bytes) return 0;
+    if (host_pinned(src, bytes)) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return 0; }
+    if (int rc = stage_reserve(ctx, true, std::min(bytes, kXferPiece))) return rc;
+    CopyPool* pool = copy_pool(ctx->up_pool);
+    if (!pool) return ICSP_ERR_MEM_ALLOC;
+    const size_t piece = std::min(ctx->gop_stage_in_cap, kXferPiece);
+    for (size_t o = 0, k = 0; o < bytes; o += piece, k++) {
+        const size_t nb = std::min(piece, bytes - o);
+        const int b = (int)(k & 1);
+        if (ctx->xfer_in_busy[b]) { HIPCHK(hipEventSynchronize(ctx->xfer_ev_in[b])); ctx->xfer_in_busy[b] = false; }
+        pool->copy(ctx->gop_stage_in[b], (const char*)src + o, nb);
+        HIPCHK(hipMemcpyAsync((char*)dst + o, ctx->gop_stage_in[b], nb, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(ctx->xfer_ev_in[b], st));
+        ctx->xfer_in_busy[b] = true;
+    }
+    return 0;
+}
+// Device -> host on `st`.  Pinned target: one asynchronous copy (the caller waits for the stream).  Anything else: through the
+// staging pair, the copy-out of a piece beside the DMA of the next; returns when `dst` holds every byte.
+int xfer_down(icsp_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st)
+{
+    if (!bytes || !dst) return 0;
+    if (host_pinned(dst, bytes)) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st)); return 0; }
+    if (int rc = stage_reserve(ctx, false, std::min(bytes, kXferPiece))) return rc;
+    CopyPool* pool = copy_pool(ctx->gop_pool);
+    if (!pool) return ICSP_ERR_MEM_ALLOC;
+    const size_t piece = std::min(ctx->gop_stage_out_cap, kXferPiece);
+    size_t prev_o = 0, prev_nb = 0;
+    for (size_t o = 0, k = 0; o < bytes; o += piece, k++) {
+        const size_t nb = std::min(piece, bytes - o);
+        const int b = (int)(k & 1);
+        HIPCHK(hipMemcpyAsync(ctx->gop_stage_out[b], (const char*)src + o, nb, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(ctx->xfer_ev_out[b], st));
+        if (k) pool->copy((char*)dst + prev_o, ctx->gop_stage_out[b ^ 1], prev_nb);       // (its DMA was waited for in the round before)
+        HIPCHK(hipEventSynchronize(ctx->xfer_ev_out[b]));
+        prev_o = o; prev_nb = nb;
+        if (o + nb >= bytes) pool->copy((char*)dst + o, ctx->gop_stage_out[b], nb);
+    }
+    return 0;
 }
 } // namespace
 
@@ -1104,10 +1237,12 @@ int icsp_device_count(void)
 void* icsp_host_alloc(size_t bytes)
 {
     void* p = nullptr;
-    return (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess) ? p : nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    pinned_ranges().add(p, bytes ? bytes : 1);
+    return p;
 }
 
-void icsp_host_free(void* p) { if (p) (void)hipHostFree(p); }
+void icsp_host_free(void* p) { if (p) { pinned_ranges().remove(p); (void)hipHostFree(p); } }
 
 // Uploads of all contexts of a device on one stream, downloads on another.  A stream's transfers go to the DMA engine its
 // first copy was given -- the lowest-numbered one idle at that moment, chosen among the engines of that copy's direction -- so
@@ -1194,14 +1329,22 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
 int icsp_host_register(void* p, size_t bytes, int read_only)
 {
     if (!p || !bytes) return ICSP_ERR_UNENOUGH_PARAM;
+    // whole pages only: a registration covers whole pages anyway, and a range that shares its first page with something else
+    // cannot be told from that something by the runtime.  The length is rounded up to the page (the caller owns the rest of its
+    // last page: true of every mapping and of aligned allocations whose size was rounded up, icsp_hip.h).
+    const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+    if ((uintptr_t)p % page) return ICSP_ERR_UNCORRECT_PARAM;
+    const size_t whole = (bytes + page - 1) / page * page;
     const unsigned flags = hipHostRegisterPortable | (read_only ? hipHostRegisterReadOnly : 0u);
-    if (hipHostRegister(p, bytes, flags) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
+    if (hipHostRegister(p, whole, flags) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
+    pinned_ranges().add(p, whole);
     return ICSP_OK;
 }
 
 int icsp_host_unregister(void* p)
 {
     if (!p) return ICSP_ERR_UNENOUGH_PARAM;
+    pinned_ranges().remove(p);
     if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
     return ICSP_OK;
 }
@@ -1259,6 +1402,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->up_stream = nullptr; ctx->down_stream = nullptr;
     ctx->gop_stage_in[0] = ctx->gop_stage_in[1] = ctx->gop_stage_out[0] = ctx->gop_stage_out[1] = nullptr;
     ctx->gop_stage_in_cap = ctx->gop_stage_out_cap = 0; memset(ctx->gop_ev, 0, sizeof(ctx->gop_ev)); ctx->gop_pool = nullptr;
+    ctx->xfer_ev_in[0] = ctx->xfer_ev_in[1] = ctx->xfer_ev_out[0] = ctx->xfer_ev_out[1] = nullptr;
+    ctx->xfer_in_busy[0] = ctx->xfer_in_busy[1] = false; ctx->up_pool = nullptr;
     ctx->s2_dirty = false; ctx->st_ahead = true; ctx->always_sync = false;
     ctx->p_dirty = false; ctx->sticky = 0;
     memset(ctx->flight, 0, sizeof(ctx->flight));
@@ -1382,10 +1527,10 @@ std::mutex g_up_turn[64];       // one upload at a time on a device's shared upl
 int copy_up(icsp_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     hipStream_t st = ctx->stream, up = ctx->up_stream;
-    if (!up) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st)); return 0; }
+    if (!up) return xfer_up(ctx, dst, src, bytes, st);
     HIPCHK(hipStreamSynchronize(st));                              // whatever still reads the destination
     std::lock_guard<std::mutex> l(g_up_turn[ctx->slot & 63]);
-    HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, up));
+    if (int rc = xfer_up(ctx, dst, src, bytes, up)) return rc;
     HIPCHK(hipStreamSynchronize(up));
     return 0;
 }
@@ -1433,8 +1578,9 @@ int icsp_upload_sync(icsp_ctx_t* ctx, const uint8_t* yuv, int first, int n)
     if (!ctx->up_stream) return ICSP_ERR_UNCORRECT_PARAM;
     if (hipSetDevice(ctx->device) != hipSuccess) return ICSP_ERR_HIP;
     std::lock_guard<std::mutex> l(g_up_turn[ctx->slot & 63]);
-    if (hipMemcpyAsync(ctx->d_frames + (size_t)first * ctx->g.fsz, yuv, (size_t)n * ctx->g.fsz, hipMemcpyHostToDevice, ctx->up_stream) != hipSuccess ||
-        hipStreamSynchronize(ctx->up_stream) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
+    // (frames that are not in pinned memory go through the context's upload staging buffers, which nothing else uses meanwhile)
+    if (int rc = xfer_up(ctx, ctx->d_frames + (size_t)first * ctx->g.fsz, yuv, (size_t)n * ctx->g.fsz, ctx->up_stream)) return rc;
+    if (hipStreamSynchronize(ctx->up_stream) != hipSuccess) { (void)hipGetLastError(); return ICSP_ERR_HIP; }
     return ICSP_OK;
 }
 
@@ -1467,11 +1613,11 @@ int icsp_download(icsp_ctx_t* ctx, int first, int n, int16_t* levels, uint8_t* a
     DownTurn turn;
     if (int rc = copy_down_begin(ctx, turn)) return rc;
     hipStream_t st = down_of(ctx);
-    if (levels) HIPCHK(hipMemcpyAsync(levels, ctx->b.levels + f * nmb * 384, c * nmb * 384 * sizeof(int16_t), hipMemcpyDeviceToHost, st));
-    if (acflag) HIPCHK(hipMemcpyAsync(acflag, ctx->b.acflag + f * nmb * 6, c * nmb * 6, hipMemcpyDeviceToHost, st));
-    if (mpm) HIPCHK(hipMemcpyAsync(mpm, ctx->b.mpm + f * nmb * 4, c * nmb * 4, hipMemcpyDeviceToHost, st));
-    if (mvd) HIPCHK(hipMemcpyAsync(mvd, ctx->b.mvd + f * nmb * 2, c * nmb * 2, hipMemcpyDeviceToHost, st));
-    if (recon) HIPCHK(hipMemcpyAsync(recon, ctx->b.recon + f * ctx->g.fsz, c * ctx->g.fsz, hipMemcpyDeviceToHost, st));
+    if (int rc = xfer_down(ctx, levels, ctx->b.levels + f * nmb * 384, c * nmb * 384 * sizeof(int16_t), st)) return rc;
+    if (int rc = xfer_down(ctx, acflag, ctx->b.acflag + f * nmb * 6, c * nmb * 6, st)) return rc;
+    if (int rc = xfer_down(ctx, mpm, ctx->b.mpm + f * nmb * 4, c * nmb * 4, st)) return rc;
+    if (int rc = xfer_down(ctx, mvd, ctx->b.mvd + f * nmb * 2, c * nmb * 2, st)) return rc;
+    if (int rc = xfer_down(ctx, recon, ctx->b.recon + f * ctx->g.fsz, c * ctx->g.fsz, st)) return rc;
     if (int rc = copy_down_end(ctx)) return rc;
     if (ctx->profiling) collect_profile(ctx);
     return ICSP_OK;
@@ -1487,9 +1633,9 @@ int icsp_upload_syntax(icsp_ctx_t* ctx, int first, int n, const int16_t* levels,
     hipStream_t st = ctx->stream;
     if (int rc = join_all(ctx)) return rc;
     ctx->st_ahead = true;
-    HIPCHK(hipMemcpyAsync(ctx->b.levels + f * nmb * 384, levels, c * nmb * 384 * sizeof(int16_t), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(ctx->b.mpm + f * nmb * 4, mpm, c * nmb * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(ctx->b.mvd + f * nmb * 2, mvd, c * nmb * 2, hipMemcpyHostToDevice, st));
+    if (int rc = xfer_up(ctx, ctx->b.levels + f * nmb * 384, levels, c * nmb * 384 * sizeof(int16_t), st)) return rc;
+    if (int rc = xfer_up(ctx, ctx->b.mpm + f * nmb * 4, mpm, c * nmb * 4, st)) return rc;
+    if (int rc = xfer_up(ctx, ctx->b.mvd + f * nmb * 2, mvd, c * nmb * 2, st)) return rc;
     HIPCHK(hipStreamSynchronize(st));
     return ICSP_OK;
 }
@@ -1643,7 +1789,7 @@ int icsp_pack_into(icsp_ctx_t* ctx, int first, int n, uint64_t at_bit, uint8_t* 
     const size_t nhead = std::min(ilo, hi) - lo, ntail = hi - std::max(ihi, lo + nhead);
     uint8_t* head = ctx->pk_host + 64;
     uint8_t* tail = ctx->pk_host + 192;                           // (head: up to 127 bytes when there is no interior)
-    if (ihi > ilo) HIPCHK(hipMemcpyAsync(dst + (ilo - lo), out + ilo, ihi - ilo, hipMemcpyDeviceToHost, st));
+    if (ihi > ilo) { if (int rc = xfer_down(ctx, dst + (ilo - lo), out + ilo, ihi - ilo, st)) return rc; }    // (an image in plain memory: staged)
     if (nhead) HIPCHK(hipMemcpyAsync(head, out + lo, nhead, hipMemcpyDeviceToHost, st));
     if (ntail) HIPCHK(hipMemcpyAsync(tail, out + hi - ntail, ntail, hipMemcpyDeviceToHost, st));
     if (int rc = copy_down_end(ctx)) return rc;
@@ -1671,7 +1817,7 @@ int icsp_pack_bits(icsp_ctx_t* ctx, int first, int n, uint8_t* body, size_t cap,
     if (nbytes > cap) { *nbits = 0; return ICSP_ERR_RANGE; }
     if (int rc = pack_write(ctx, first, n, 0)) return rc;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemcpyAsync(body, ctx->pk.out, nbytes, hipMemcpyDeviceToHost, st));
+    if (int rc = xfer_down(ctx, body, ctx->pk.out, nbytes, st)) return rc;
     HIPCHK(hipStreamSynchronize(st));
     if (ctx->profiling) collect_profile(ctx);
     return ICSP_OK;
@@ -1689,6 +1835,7 @@ int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes)
     if (int rc = pack_alloc(ctx)) return rc;
     const size_t nb = std::min(bytes, (size_t)16 << 20), piece = std::min(nb, ctx->pk_cap);
     if (nb == 0) return ICSP_OK;
+    if (!host_pinned(pinned, nb)) return ICSP_ERR_UNCORRECT_PARAM;      // this call is about a pinned range's first use; plain memory has none
     ctx->pk_first = -1;                                 // the scratch no longer holds a counted string
     HIPCHK(hipMemsetAsync(ctx->pk.out, 0, piece, ctx->stream));
     for (size_t o = 0; o < nb; o += piece)
@@ -1744,22 +1891,6 @@ int icsp_prepare(icsp_ctx_t* ctx)
 }
 
 namespace {
-// Is [p, p + bytes) pinned host memory (hipHostMalloc / hipHostRegister), i.e. can a DMA engine reach it directly?
-bool host_pinned(const void* p, size_t bytes)
-{
-    if (!p || !bytes) return true;
-    // (both ends and sixteen places in between: a registration covers whole pages, so a plain buffer may start or end inside a
-    //  neighbour's registered page)
-    hipPointerAttribute_t a;
-    for (int k = 0; k <= 17; k++) {
-        const char* q = (const char*)p + (k == 17 ? bytes - 1 : (size_t)((unsigned __int128)(bytes - 1) * k / 17));
-        memset(&a, 0, sizeof(a));
-        if (hipPointerGetAttributes(&a, q) != hipSuccess) { (void)hipGetLastError(); return false; }      // unknown to the runtime: pageable
-        if (a.type != hipMemoryTypeHost) return false;
-    }
-    return true;
-}
-
 // The one-call host path as a pipeline: the frames go up chunk by chunk (whole GOPs) on the device's upload stream from a helper
 // thread, every chunk is encoded as soon as it is there, and its levels and reconstruction come down on the device's download
 // stream while the next chunk is being encoded and the one after it uploaded -- transfers in both directions and kernels side by
@@ -1823,24 +1954,10 @@ int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* levels, uint
     const bool lv_direct = host_pinned(levels, (size_t)n * lvf), rc_direct = host_pinned(recon, (size_t)n * fsz);
     const size_t need_in = in_direct ? 0 : (size_t)cf * fsz;
     const size_t need_out = ((levels && !lv_direct) ? (size_t)cf * lvf : 0) + ((recon && !rc_direct) ? (size_t)cf * fsz : 0);
-    if (need_in > ctx->gop_stage_in_cap || need_out > ctx->gop_stage_out_cap) {
-        for (int k = 0; k < 2; k++) {
-            if (need_in > ctx->gop_stage_in_cap) {
-                if (ctx->gop_stage_in[k]) (void)hipHostFree(ctx->gop_stage_in[k]);
-                ctx->gop_stage_in[k] = nullptr;
-                if (hipHostMalloc((void**)&ctx->gop_stage_in[k], need_in, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->gop_stage_in[k] = nullptr; ctx->gop_stage_in_cap = 0; ctx->err = "hipHostMalloc staging (in)"; return ICSP_ERR_MEM_ALLOC; }
-            }
-            if (need_out > ctx->gop_stage_out_cap) {
-                if (ctx->gop_stage_out[k]) (void)hipHostFree(ctx->gop_stage_out[k]);
-                ctx->gop_stage_out[k] = nullptr;
-                if (hipHostMalloc((void**)&ctx->gop_stage_out[k], need_out, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->gop_stage_out[k] = nullptr; ctx->gop_stage_out_cap = 0; ctx->err = "hipHostMalloc staging (out)"; return ICSP_ERR_MEM_ALLOC; }
-            }
-        }
-        ctx->gop_stage_in_cap = std::max(ctx->gop_stage_in_cap, need_in); ctx->gop_stage_out_cap = std::max(ctx->gop_stage_out_cap, need_out);
-    }
-    const unsigned hw = std::max(2u, std::thread::hardware_concurrency());
-    if ((need_in || need_out) && !ctx->gop_pool) ctx->gop_pool = new (std::nothrow) CopyPool((int)std::min(5u, hw / 2));
-    if ((need_in || need_out) && !ctx->gop_pool) return ICSP_ERR_MEM_ALLOC;
+    xfer_in_drain(ctx);                                            // (an earlier staged upload may still be reading the buffers)
+    if (need_in) { if (int rc = stage_reserve(ctx, true, need_in)) return rc; }
+    if (need_out) { if (int rc = stage_reserve(ctx, false, need_out)) return rc; }
+    if ((need_in || need_out) && !copy_pool(ctx->gop_pool)) return ICSP_ERR_MEM_ALLOC;
 
     // ---- uploader thread: chunk after chunk onto the device's upload stream (one transfer at a time per stream: copy_up's rule)
     std::mutex um; std::condition_variable ucv;
@@ -1929,30 +2046,8 @@ int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* levels, uint
         if (!dst || !bytes) return 0;
         DownTurn turn;
         if (int r2 = copy_down_begin(ctx, turn)) return r2;
-        hipStream_t ds = down_of(ctx);
-        if (host_pinned(dst, bytes)) {
-            HIPCHK(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, ds));
-            return copy_down_end(ctx);
-        }
-        if (!ctx->gop_stage_out[0] || ctx->gop_stage_out_cap < ((size_t)1 << 20)) {                 // (all big results were pinned: no staging buffer yet)
-            for (int k = 0; k < 2; k++) {
-                if (ctx->gop_stage_out[k]) (void)hipHostFree(ctx->gop_stage_out[k]);
-                ctx->gop_stage_out[k] = nullptr;
-                if (hipHostMalloc((void**)&ctx->gop_stage_out[k], (size_t)4 << 20, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->gop_stage_out[k] = nullptr; ctx->gop_stage_out_cap = 0; ctx->err = "hipHostMalloc staging (out)"; return ICSP_ERR_MEM_ALLOC; }
-            }
-            ctx->gop_stage_out_cap = (size_t)4 << 20;
-        }
-        if (!ctx->gop_pool) ctx->gop_pool = new (std::nothrow) CopyPool((int)std::min(5u, hw / 2));
-        if (!ctx->gop_pool) return ICSP_ERR_MEM_ALLOC;
-        const size_t piece = ctx->gop_stage_out_cap;
-        for (size_t o = 0, k = 0; o < bytes; o += piece, k++) {                                      // transfer of piece k beside the copy of piece k - 1
-            const size_t nb = std::min(piece, bytes - o);
-            HIPCHK(hipMemcpyAsync(ctx->gop_stage_out[k & 1], (const char*)dev + o, nb, hipMemcpyDeviceToHost, ds));
-            if (k) ctx->gop_pool->copy((char*)dst + o - piece, ctx->gop_stage_out[(k - 1) & 1], piece);
-            HIPCHK(hipStreamSynchronize(ds));
-            if (o + nb >= bytes) ctx->gop_pool->copy((char*)dst + o, ctx->gop_stage_out[k & 1], nb);
-        }
-        return 0;
+        if (int r2 = xfer_down(ctx, dst, dev, bytes, down_of(ctx))) return r2;
+        return copy_down_end(ctx);
     };
     const size_t nmb6 = (size_t)n * nmb;
     if (int r2 = fetch(acflag, ctx->b.acflag, nmb6 * 6)) return r2;
@@ -2061,8 +2156,8 @@ int icsp_download_debug(icsp_ctx_t* ctx, int first, int n, int8_t* mv, uint8_t* 
     HIPCHK(hipSetDevice(ctx->device));
     const size_t nmb = ctx->g.nmb, f = first, c = n;
     if (int rc = join_all(ctx)) return rc;
-    if (mv) HIPCHK(hipMemcpyAsync(mv, ctx->b.mv + f * nmb * 2, c * nmb * 2, hipMemcpyDeviceToHost, ctx->stream));
-    if (imode) HIPCHK(hipMemcpyAsync(imode, ctx->b.imode + f * nmb * 4, c * nmb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = xfer_down(ctx, mv, ctx->b.mv + f * nmb * 2, c * nmb * 2, ctx->stream)) return rc;
+    if (int rc = xfer_down(ctx, imode, ctx->b.imode + f * nmb * 4, c * nmb * 4, ctx->stream)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ICSP_OK;
 }
@@ -2088,7 +2183,7 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first, int n, double* coef)
     HIPCHK(hipSetDevice(ctx->device));
     const size_t per = (size_t)ctx->g.nmb * 384;
     if (int rc = join_all(ctx)) return rc;
-    HIPCHK(hipMemcpyAsync(coef, ctx->b.coef + (size_t)first * per, (size_t)n * per * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (int rc = xfer_down(ctx, coef, ctx->b.coef + (size_t)first * per, (size_t)n * per * sizeof(double), ctx->stream)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return ICSP_OK;
 }
@@ -2151,6 +2246,8 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
     ctx->gop_stage_in[0] = ctx->gop_stage_in[1] = ctx->gop_stage_out[0] = ctx->gop_stage_out[1] = nullptr;
     ctx->gop_stage_in_cap = ctx->gop_stage_out_cap = 0; memset(ctx->gop_ev, 0, sizeof(ctx->gop_ev)); ctx->gop_pool = nullptr;
+    ctx->xfer_ev_in[0] = ctx->xfer_ev_in[1] = ctx->xfer_ev_out[0] = ctx->xfer_ev_out[1] = nullptr;
+    ctx->xfer_in_busy[0] = ctx->xfer_in_busy[1] = false; ctx->up_pool = nullptr;
     ctx->force_intra_group = 0; ctx->intra_waves_g4 = ctx->intra_waves_g2 = 0; ctx->last_rowgroup = 0;
     ctx->s2_dirty = ctx->st_ahead = ctx->always_sync = ctx->p_dirty = false;
     ctx->keep_coef = ctx->profiling = false; ctx->prof_mask = 0;

@@ -215,25 +215,32 @@ int icsp_bitstream_header(const icsp_params_t* params, uint64_t total_bits, uint
 int icsp_bitstream_place(uint8_t* image, size_t cap, uint64_t bit_offset, const uint8_t* piece, uint64_t piece_bits);
 int icsp_bitstream_end(uint8_t* image, uint64_t total_bits);
 
-/* ---- pinned host memory for the transfers (hipHostMalloc): uploads and downloads from/to it run at PCIe speed and
- *      overlap with kernels of other contexts; any host pointer works with every call, pageable ones are staged by the
- *      runtime.  NULL when there is no device or no memory. ---- */
+/* ---- host memory and the transfers.  Every call that takes a host pointer works with any memory.  What the library KNOWS to be
+ *      pinned -- ranges of icsp_host_alloc and icsp_host_register, and ranges for which the runtime names one allocation that
+ *      covers them whole (someone else's hipHostMalloc) -- is the source / target of the DMA itself: PCIe speed, beside the
+ *      kernels of other contexts.  Everything else goes through two pinned staging buffers per direction inside the library
+ *      (helper threads copy a piece beside the transfer of the piece before): the HIP runtime is never handed a plain caller
+ *      pointer.  (It would pin such a buffer on the fly and cache the pin; in a long-lived process whose heap ranges are trimmed
+ *      and mapped again a later transfer then faults on the device -- round 4, tools/repro_fault.py.)  NULL when there is no
+ *      device or no memory. ---- */
 void* icsp_host_alloc(size_t bytes);
 void icsp_host_free(void* p);
 /* Pin a range the caller already owns (hipHostRegister) -- in particular a mapping of the input file (read_only != 0: mapped
  * without write permission) or of the output file (MAP_SHARED, pages populated): icsp_upload then reads the frames and
  * icsp_download writes the reconstruction by DMA from/into the page cache, with no staging copy on the host (the reference's
  * YCbCrLoad fread, ENC:247-283, and checkResultFrames fwrite, ENC:6376-6413, become the transfers themselves).  The range is
- * usable from every device.  ICSP_ERR_HIP when the runtime refuses the range (callers fall back to staging buffers).
- * Register WHOLE PAGES that belong to the range alone (a mapping, posix_memalign(4096) with the size rounded up): a registration
- * covers whole pages, and the runtime treats any buffer that starts inside a registered page as pinned -- an unrelated heap
- * allocation sharing the last page of an unaligned registered one is then written by DMA as if pinned, and the device faults where
- * the registration ends (seen in round 4 with registered numpy heap arrays; not a property of this library's transfers). */
+ * usable from every device.
+ * `p` must lie on a page boundary (ICSP_ERR_UNCORRECT_PARAM otherwise); `bytes` is rounded up to whole pages, which must be the
+ * caller's own to the end of the last one (true of every mapping, and of posix_memalign(4096, ...) blocks whose size was rounded
+ * up).  ICSP_ERR_HIP when the runtime refuses the range (callers fall back to plain memory, i.e. the library's staging).
+ * Unregister a range BEFORE its memory is freed or unmapped: a registration that outlives its pages makes the runtime treat
+ * whatever is mapped there next as pinned.  Buffers that merely start or end inside a registered page are not treated as pinned
+ * by this library (they are staged), whatever the runtime reports for their first byte. */
 int icsp_host_register(void* p, size_t bytes, int read_only);
 int icsp_host_unregister(void* p);
 /* Spends a pinned range's first-use cost now: the context's stream writes `bytes` zero bytes (at most 16 MB) to it by DMA.  For
  * ranges that must start out zeroed anyway, i.e. the body image icsp_pack_into fills (a stream's first large transfer into a
- * newly pinned range can cost the call about 6 ms). */
+ * newly pinned range can cost the call about 6 ms).  ICSP_ERR_UNCORRECT_PARAM for memory the library does not know to be pinned. */
 int icsp_host_warm(icsp_ctx_t* ctx, void* pinned, size_t bytes);
 /* Several contexts on one device: a stream's transfers go to the DMA engine the runtime gave its FIRST copy -- the lowest-
  * numbered engine idle at that moment -- so contexts set up one after the other on an idle device all share one engine, and

@@ -275,3 +275,67 @@ def test_encode_gop_large_frames_pipeline():
     enc.close()
     for k in ("levels", "acflag", "mpm", "mvd", "recon"):
         assert np.array_equal(got[k], want[k]), k
+
+
+# ---- caller memory the library does not KNOW to be pinned never reaches the runtime as a plain pointer (the
+#      round-4 device fault).  The session runs WITHOUT the mallopt hook round 4's conftest.py had.
+def test_register_refuses_a_range_that_does_not_start_on_a_page():
+    raw = np.zeros(3 * 4096, np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    lib = capi.load()
+    assert lib.icsp_host_register(capi._vp(raw[off + 8:]), 4096, 0) == 2          # ICSP_ERR_UNCORRECT_PARAM
+    assert lib.icsp_host_register(capi._vp(raw[off:]), 5000, 0) == 0              # a ragged length is rounded up to the page
+    assert lib.icsp_host_unregister(capi._vp(raw[off:])) == 0
+
+
+def test_plain_buffer_that_starts_inside_a_registered_page_is_staged():
+    """Round 4's trigger: the runtime reports any pointer inside a registered page as pinned, so a plain buffer that starts there and
+    ends beyond the registration was DMA'd as if pinned and the device faulted where the registration ends.  Both directions."""
+    n, q = 64, 16
+    clip = clipgen.synth_clip("foremanlike", n)
+    ref = capi.Encoder(W, H, q, q, 0, max_frames=n)
+    want = ref.encode(clip)
+    ref.close()
+    fsz = clip.shape[1]
+    nb = n * fsz
+    raw = np.empty(((2 * nb + 4095) // 4096 + 2) * 4096, np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    pages = raw[off:]
+    half = 16 * 4096
+    assert capi.host_register(pages[:half])
+    try:
+        src = pages[half - 100: half - 100 + nb].reshape(n, fsz)                   # starts 100 bytes before the registration ends
+        src[:] = clip
+        enc = capi.Encoder(W, H, q, q, 0, max_frames=n)
+        assert enc.lib.icsp_upload(enc.ctx, capi._vp(src), 0, n) == 0
+        enc.encode_resident(0, n)
+        dst = pages[half - 4000: half - 4000 + nb].reshape(n, fsz)
+        dst[:] = 0
+        assert enc.lib.icsp_download(enc.ctx, 0, n, None, None, None, None, capi._vp(dst)) == 0
+        assert np.array_equal(dst, want["recon"])
+        got = enc.encode(src)                                                      # the one-call pipeline decides per array too
+        enc.close()
+        _same(got, want, "straddling source: ")
+    finally:
+        assert capi.host_unregister(pages[:half])
+
+
+def test_host_warm_refuses_plain_memory():
+    enc = capi.Encoder(W, H, 16, 16, 0, max_frames=2)
+    plain = np.zeros(1 << 20, np.uint8)
+    assert enc.lib.icsp_host_warm(enc.ctx, capi._vp(plain), plain.size) == 2       # ICSP_ERR_UNCORRECT_PARAM
+    enc.close()
+
+
+def test_fault_reproducer_runs_clean_bounded():
+    """tools/repro_fault.py (heap churn of 50-300 MB frame arrays, plain pointers, contexts created and destroyed, registered ranges in
+    play) for a few seconds per mode, each in a process of its own: no device fault, every checked transfer exact."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("plain", "regsplit"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "repro_fault.py"), mode, "4"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (mode, r.returncode, r.stderr[-400:])
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["status"] == "ok" and line["rounds"] >= 2, line
