@@ -163,6 +163,8 @@ struct Geo {
     int bands;                        // tall frames: the DC chain's bands as waves of one continued wavefront (ICSP_SERIAL_BANDS)
     uint32_t mdc, mac;                // floor(2^32/q) + 1: |t|/q == umulhi(|t|, m) for |t| < 2^16, q > 1
     uint32_t msw, mtpr;               // the same for sw and for the tiles per row (sw + 1) / 2: n / sw == umulhi(n, msw) for n < 2^16
+    int qpow2;                        // both quantiser steps are powers of two: the quantiser is one fused multiply-add + one conversion (quant_pow2)
+    double idc, iac;                  //   1 / qdc, 1 / qac (exact then)
     long long fsz;                    // bytes per frame = W*H*3/2
 };
 struct FrameSel { int first, stride, count; };     // item i -> frame slot first + i*stride
@@ -1389,6 +1391,9 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     // strictly above 2^32/q, which the signed form in the DC chains needs (a negative multiple of q must not divide exactly)
     g.mdc = (uint32_t)(0x100000000ull / (unsigned)g.qdc + 1);               // unused when q == 1 (would not fit 32 bits)
     g.mac = (uint32_t)(0x100000000ull / (unsigned)g.qac + 1);
+    g.qpow2 = ((g.qdc & (g.qdc - 1)) == 0 && (g.qac & (g.qac - 1)) == 0) ? 1 : 0;
+    { int v_ = g.qpow2; if (!env_int("ICSP_QUANT_POW2", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } g.qpow2 = g.qpow2 && v_; }
+    g.idc = 1.0 / (double)g.qdc; g.iac = 1.0 / (double)g.qac;
     g.msw = (uint32_t)(0x100000000ull / (unsigned)g.sw + 1);
     g.mtpr = (uint32_t)(0x100000000ull / (unsigned)((g.sw + 1) / 2) + 1);
     g.fsz = (long long)g.W * g.H * 3 / 2;

@@ -51,6 +51,8 @@
  *   ICSP_FAKE_DEVICES 2..64 (test hook, read once per process) the library presents that many devices, device d being physical device
  *                        d mod (real devices) with per-device records of its own (search tables, shared transfer streams, turns):
  *                        the multi-device paths of a host run on a one-GPU box
+ *   ICSP_QUANT_POW2 0|1  1 (default): quantiser steps that are both powers of two take the add / multiply / truncate form of the
+ *                        quantiser in the 8-lane transform chain (oracle/fma_proof.c); 0: the multiply-high division for every step
  *   ICSP_XCD_SLICES 0..64 bands a frame is cut into when a P step's workgroups are dealt over the XCDs (0 = automatic; rounded down to a power of two)
  * Launch path: a failed kernel launch, event record or cross-stream wait could silently drop an ordering edge and yield
  * wrong bits, so it POISONS the context: that call and every later call on the context return ICSP_ERR_HIP

@@ -32,6 +32,8 @@ void ref_dct_block(const int in[64], double out[64]);
 void ref_cdct_block(const int in[64], double out[64]);
 void ref_idct_block(const int in[64], double out[64]);
 void ref_cidct_block(const int in[64], double out[64]);
+void ref_quant_luma(const double coef[64], int qdc, int qac, int q[64], int zz[64], int iq[64], int* acflag);
+void ref_quant_chroma(const double coef[64], int qdc, int qac, int q[64], int zz[64], int iq[64], int* acflag);
 
 static double g_cos[8][8], g_irt2;
 
@@ -159,7 +161,56 @@ int main(int argc, char** argv)
         idct_variant(in, plain, 0, 0, (const double (*)[8])dcos); idct_variant(in, got, 1, 0, (const double (*)[8])dcos);
         brk_dec += diff_bits(plain, got) != 0;
     }
+    /* The quantiser for POWER-OF-TWO steps (round 5; icsp_blk8.hip.inc, quant_pow2): the reference computes
+     *   luma    (int)(c + 0.5) / q           (ENC:2780: cast truncates, integer division truncates)
+     *   chroma  (int)floor(c + 0.5) / q      (ENC:4642)
+     * With x = rn(c + 0.5): trunc(trunc(x) / q) == trunc(x / q) for every integer q >= 1 and either sign; for q = 2^s the
+     * scaling x * 2^-s is exact: trunc((c + 0.5) * 2^-s), add, multiply, truncating conversion (what the kernels do); it also
+     * commutes with the rounding of the sum, rn(c + 0.5) * 2^-s == fma(c, 2^-s, 2^-(s+1)).  Chroma: trunc(floor(x) * 2^-s).
+     * Checked against the reference's own Quantization_block / CQuantization_block on coefficients that sit on, just below
+     * and just above every rounding and division boundary, and on random ones. */
+    long bad_ql = 0, bad_qc = 0, nq = 0;
+    {
+        double coef[64];
+        int lv[64], zz[64], iq[64], acf;
+        for (long n = 0; n < nblk / 16 + 64; n++) {
+            const int sdc = (int)(rnd() % 8), sac = (int)(rnd() % 8);
+            const int qdc = 1 << sdc, qac = 1 << sac;
+            for (int i = 0; i < 64; i++) {
+                const int q = i ? qac : qdc;
+                const uint32_t kind = rnd() % 6;
+                double c;
+                if (kind == 0) c = ((double)(rnd() % 4000001) - 2000000.0) / 1000.0 * 4.0;                    /* anywhere in +-8000 */
+                else {
+                    /* near k*q - 0.5 (the division boundary after rounding) or k - 0.5 (the rounding boundary) */
+                    const long k = (long)(rnd() % 2001) - 1000;
+                    const double b = (kind & 1) ? (double)(k * q) - 0.5 : (double)k - 0.5;
+                    const int e = (int)(rnd() % 5) - 2;
+                    c = b;
+                    for (int t = 0; t < (e < 0 ? -e : e); t++) c = nextafter(c, e < 0 ? -1e9 : 1e9);
+                    if (kind == 5) c = b + ((double)(rnd() % 2001) - 1000.0) * 1e-9;
+                }
+                coef[i] = c;
+            }
+            ref_quant_luma(coef, qdc, qac, lv, zz, iq, &acf);
+            for (int i = 0; i < 64; i++) {
+                const double inv = 1.0 / (double)(i ? qac : qdc);
+                const int got = (int)fma(coef[i], inv, 0.5 * inv), got2 = (int)((coef[i] + 0.5) * inv);     /* the kernels use the second form */
+                bad_ql += got != lv[i] || got2 != lv[i];
+            }
+            ref_quant_chroma(coef, qdc, qac, lv, zz, iq, &acf);
+            for (int i = 0; i < 64; i++) {
+                const double inv = 1.0 / (double)(i ? qac : qdc);
+                const int got = (int)(floor(coef[i] + 0.5) * inv);
+                bad_qc += got != lv[i];
+            }
+            nq++;
+        }
+    }
     printf("blocks %ld\n", nblk);
+    printf("quantiser blocks %ld (power-of-two steps 1..128)\n", nq);
+    printf("luma   quantiser (c+.5)*inv, fma vs Quantization_block: %ld levels differ (must be 0)\n", bad_ql);
+    printf("chroma quantiser floor*inv vs CQuantization_block : %ld levels differ (must be 0)\n", bad_qc);
     printf("forward  pass-1 fused vs DCT_block   : %ld blocks differ (must be 0)\n", bad_f);
     printf("forward  pass-1 fused vs CDCT_block  : %ld blocks differ (must be 0)\n", bad_fc);
     printf("forward  pass-1 folded vs DCT_block  : %ld blocks differ (must be 0)\n", bad_fold);
@@ -169,5 +220,5 @@ int main(int argc, char** argv)
     printf("forward  pass-2 fused too            : %ld blocks differ (expected > 0: not bit-safe)\n", brk_f2);
     printf("inverse  pass-2 fused too            : %ld blocks differ (expected > 0: not bit-safe)\n", brk_i2);
     printf("decoder table, inverse pass-1 fused  : %ld blocks differ (expected > 0: not bit-safe)\n", brk_dec);
-    return (bad_f || bad_fc || bad_i || bad_ic || bad_fold || bad_foldc) ? 1 : 0;
+    return (bad_f || bad_fc || bad_i || bad_ic || bad_fold || bad_foldc || bad_ql || bad_qc) ? 1 : 0;
 }

@@ -18,6 +18,8 @@ PROOF = os.path.join(po.REF_DIR, "fma_proof")
 def test_first_pass_fma_is_bit_identical_to_reference_objects():
     r = subprocess.run([PROOF, "1000000", "20261003"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
+    quant = re.findall(r"(\d+) levels differ \(must be 0\)", r.stdout)      # round 5: the power-of-two quantiser as fma + truncating conversion
+    assert len(quant) == 2 and all(int(x) == 0 for x in quant), r.stdout
     must = re.findall(r"(\d+) blocks differ \(must be 0\)", r.stdout)
     assert len(must) == 6 and all(int(x) == 0 for x in must), r.stdout      # fused x4, folded forward pass 1 x2
     broken = re.findall(r"(\d+) blocks differ \(expected > 0", r.stdout)
