@@ -178,6 +178,11 @@ struct DevBufs {
     int16_t* me_sums;                 // [slot][nmb][4][6] residual block sums of a P-frame MB for each search state
     int16_t* dcpred;                  // [slot][nmb][6] DC predictors
     double* coef;                     // optional [slot][nmb][6][64]
+    // half-frame units of the intra luma kernel (k_intra_luma8<.., SPLIT>): hand-off granules [slot][cols8][3], ticket counters (one per
+    // stream of the context), sticky "a wait ran out" word
+    unsigned long long* xhand;
+    unsigned* xticket;
+    int* xerr;
 };
 
 // ------------------------------------------------------------------------------------------------ wave helpers
@@ -389,6 +394,12 @@ struct icsp_ctx {
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
     int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
     int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
+    int intra_split;                  // ICSP_INTRA_SPLIT: the pairs form as two workgroups per frame (1: wherever it can be built, 0: never; default: launch_intra_luma's rule)
+    unsigned split_epoch;             // tag of the last split launch's hand-off granules
+    unsigned split_tickets[4];        // tickets drawn so far from each of the four counters (0: stream, 1 / 2: group streams, 3: stream2)
+    bool split_used;                  // a split launch has been made since icsp_sync last looked at b.xerr
+    int* xerr_host;                   // pinned word for that look
+    int last_split;
     int force_intra_group;            // ICSP_INTRA_GROUP: 8-lane form with block rows chained in groups of 4 (4), the plain wavefront (1), or chosen (0)
     int intra_waves_g4, intra_waves_g2;   // waves of eight blocks that the widest step of the chained wavefront needs (groups of four / two rows)
     int i_groups;                     // ICSP_I_GROUPS: parts an all-intra batch of more frames than CUs is launched in (1 or 2)
@@ -540,18 +551,21 @@ int intra_waves_needed(const Geo& g)
 
 // the 8-lane kernel with block rows chained in groups of gc (k_intra_luma8<.., gc>): waves of eight slots that the widest step needs,
 // slots starting at a multiple of gc
-int intra_waves_chained(const Geo& g, int gc)
+int intra_waves_chained(const Geo& g, int gc, int rows = 0)         // rows: of a part of the frame (half-frame units); 0: the whole frame
 {
     int widest = 0;
-    const int nsteps = g.cols8 + (g.rows8 - 1) + (g.rows8 - 1) / gc;
+    const int rows8 = rows ? rows : g.rows8;
+    const int nsteps = g.cols8 + (rows8 - 1) + (rows8 - 1) / gc;
     for (int t = 0; t < nsteps; t++) {
         const int tp = t - (g.cols8 - 1);
         const int r_first = tp <= 0 ? 0 : gc * (tp / (gc + 1)) + std::min(tp % (gc + 1), gc);
-        const int r_last = std::min(g.rows8 - 1, gc * (t / (gc + 1)) + std::min(t % (gc + 1), gc - 1));
+        const int r_last = std::min(rows8 - 1, gc * (t / (gc + 1)) + std::min(t % (gc + 1), gc - 1));
         widest = std::max(widest, r_last - (r_first & ~(gc - 1)) + 1);
     }
     return (widest + 7) / 8;
 }
+// block rows of the upper half of a frame encoded as two units: half the rows, a whole number of pairs
+inline int split_rows(const Geo& g) { return (g.rows8 / 2) & ~1; }
 
 void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma = false, bool beside_p_steps = false);
 
@@ -905,6 +919,12 @@ template <int NW, int GC> void launch_intra8_g(const Geo& g, const FrameSel& fs,
     const size_t lds = intra8_lds_bytes(g, 4) + (size_t)ring_slots_exact(NW) * 64 * kRingBlocks;
     hipLaunchKernelGGL((k_intra_luma8<NW, true, GC>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
 }
+// the pairs form as two workgroups per frame (IntraSplit): 2 G units handed out by ticket
+template <int NW> void launch_intra8_split(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, const IntraSplit& sp, hipStream_t st)
+{
+    const size_t lds = intra8_lds_bytes(g, 4) + (size_t)ring_slots_exact(NW) * 64 * kRingBlocks;
+    hipLaunchKernelGGL((k_intra_luma8s<NW>), dim3(2 * G), dim3(NW * 64), lds, st, g, fs, b, sp);
+}
 template <int GC> void launch_intra8_chained(int nw, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
     if (nw <= 1)       launch_intra8_g<1, GC>(g, fs, b, G, st);
@@ -961,6 +981,25 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
     const int nwc = gc == 4 ? ctx->intra_waves_g4 : gc == 2 ? ctx->intra_waves_g2 : 0;
     bool chained = gc != 0;
     if (chained && (nwc < 1 || nwc > 8 || !ctx->intra_ring || (ctx->force_intra_nw && ctx->force_intra_nw < nwc) || ctx->force_intra_form == 32)) chained = false;
+    ctx->last_split = 0;
+    if (chained && gc == 2 && ctx->intra_split == 1 && !ctx->force_intra_nw && split_rows(g) >= 2 && g.cols8 >= 2) {
+        // two units per frame (k_intra_luma8<.., SPLIT>)
+        const int hr = split_rows(g);
+        const int nw = std::max(intra_waves_chained(g, 2, hr), intra_waves_chained(g, 2, g.rows8 - hr));
+        if (nw <= 6) {
+            int tix = st == ctx->stream ? 0 : st == ctx->pstream[1] ? 1 : st == ctx->pstream[2] ? 2 : 3;
+            if (++ctx->split_epoch == 0) ctx->split_epoch = 1;      // (2^32 split launches later a stale tag could match: by then every granule of a live slot has been rewritten many times over)
+            IntraSplit sp{ hr, ctx->split_epoch, ctx->split_tickets[tix], tix };
+            ctx->split_tickets[tix] += 2u * (unsigned)G;
+            ctx->split_used = true;
+            ctx->last_form = 8; ctx->last_nw = nw; ctx->last_ring = true; ctx->last_rowgroup = 2; ctx->last_split = 1;
+            if (nw <= 2)      launch_intra8_split<2>(g, fs, b, G, sp, st);
+            else if (nw <= 3) launch_intra8_split<3>(g, fs, b, G, sp, st);
+            else if (nw <= 4) launch_intra8_split<4>(g, fs, b, G, sp, st);
+            else              launch_intra8_split<6>(g, fs, b, G, sp, st);
+            return;
+        }
+    }
     if (chained) {
         const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : nwc;
         ctx->last_form = 8; ctx->last_nw = nw; ctx->last_ring = true; ctx->last_rowgroup = gc;
@@ -1420,6 +1459,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
     ctx->force_intra_nw = 0; ctx->force_intra_form = 0; ctx->force_intra_group = 0; ctx->last_rowgroup = 0;
+    ctx->intra_split = 0; ctx->split_epoch = 0; memset(ctx->split_tickets, 0, sizeof(ctx->split_tickets)); ctx->split_used = false; ctx->xerr_host = nullptr; ctx->last_split = 0;
+    if (!env_int("ICSP_INTRA_SPLIT", 0, 1, &ctx->intra_split)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured (300 CIF frames, period 10): 1 group 0.75 M frames/s, 2 groups 0.89 M, 3 groups -- a fourth
                                        // busy stream of the context -- 0.27 M, whatever the stream priorities and GPU_MAX_HW_QUEUES
@@ -1467,7 +1508,12 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ALLOC(ctx->b.me_flag, nf * sizeof(int));
     ALLOC(ctx->b.me_done, nf * sizeof(int));
     ALLOC(ctx->b.dcpred, nf * nmb * 6 * sizeof(int16_t));
+    ALLOC(ctx->b.xhand, nf * (size_t)g.cols8 * 3 * sizeof(unsigned long long));
+    ALLOC(ctx->b.xticket, 16 * sizeof(unsigned));         // four counters + the sticky error word behind them (one small block)
+    ctx->b.xerr = (int*)(ctx->b.xticket + 8);
 #undef ALLOC
+    if ((e = hipHostMalloc((void**)&ctx->xerr_host, 64, hipHostMallocDefault)) != hipSuccess) return fail(ICSP_ERR_MEM_ALLOC, "hipHostMalloc xerr", e);
+    *ctx->xerr_host = 0;
     phase("13 hipMalloc");
 #define ZERO(ptr, bytes) if ((e = hipMemsetAsync((ptr), 0, (bytes), ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipMemsetAsync " #ptr, e)
     ZERO(ctx->b.me_flag, nf * sizeof(int));            // k_me raises it, the serial kernel of the same step clears it
@@ -1476,6 +1522,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ZERO(ctx->b.mvd, nf * nmb * 2);
     ZERO(ctx->b.mv, nf * nmb * 2);
     ZERO(ctx->b.imode, nf * nmb * 4);
+    ZERO(ctx->b.xhand, nf * (size_t)g.cols8 * 3 * sizeof(unsigned long long));     // tag 0 is never a launch's epoch
+    ZERO(ctx->b.xticket, 16 * sizeof(unsigned));
 #undef ZERO
     phase("6 hipMemsetAsync (enqueue)");
     {   // the search tables are the same for every context: once per device and process (the call costs 7-12 ms)
@@ -1508,10 +1556,11 @@ int icsp_destroy(icsp_ctx_t* ctx)
     for (auto& e : ctx->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     void* bufs[] = { ctx->d_frames, ctx->b.recon, ctx->b.levels, ctx->b.acflag, ctx->b.mpm, ctx->b.mvd, ctx->b.mv, ctx->b.imode, ctx->b.me_ent,
-                     ctx->b.me_sums, ctx->b.me_flag, ctx->b.me_done, ctx->b.dcpred, ctx->b.coef, ctx->pk.grp_bits, ctx->pk.grp_off,
+                     ctx->b.me_sums, ctx->b.me_flag, ctx->b.me_done, ctx->b.dcpred, ctx->b.coef, ctx->b.xhand, ctx->b.xticket, ctx->pk.grp_bits, ctx->pk.grp_off,
                      ctx->pk.chunk_bits, ctx->pk.chunk_base, ctx->pk.out };
     for (void* q : bufs) if (q) (void)hipFree(q);
     if (ctx->pk_host) (void)hipHostFree(ctx->pk_host);
+    if (ctx->xerr_host) (void)hipHostFree(ctx->xerr_host);
     gop_release(ctx);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -1602,7 +1651,14 @@ int icsp_sync(icsp_ctx_t* ctx)
     ENTER(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     if (int rc = join_all(ctx)) return rc;
+    if (ctx->split_used) {
+        // half-frame units: did a lower half give up waiting for its upper half (k_intra_luma8<.., SPLIT>, kSplitSpinMax)?  Its
+        // results are wrong then; the context is unusable
+        HIPCHK(hipMemcpyAsync(ctx->xerr_host, ctx->b.xerr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        ctx->split_used = false;
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (*ctx->xerr_host) { ctx->err = "k_intra_luma8 (half-frame units): a wait for the upper half ran out"; ctx->sticky = ICSP_ERR_HIP; return ICSP_ERR_HIP; }
     // event pairs are read out in icsp_profile_get / icsp_profile_reset, not here: a caller timing "launch ... icsp_sync"
     // must not pay for the bookkeeping of the profiler
     return ICSP_OK;
@@ -2125,6 +2181,14 @@ int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, i
     return ICSP_OK;
 }
 
+// 1 when the last intra luma launch ran as half-frame units (k_intra_luma8s), else 0
+int icsp_debug_last_split(icsp_ctx_t* ctx, int* split)
+{
+    ENTER(ctx);
+    if (split) *split = ctx->last_split;
+    return ICSP_OK;
+}
+
 int icsp_device_pci_bus_id(int device, char* out, int cap)
 {
     if (!out || cap < 13) return ICSP_ERR_RANGE;
@@ -2254,6 +2318,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->xfer_ev_in[0] = ctx->xfer_ev_in[1] = ctx->xfer_ev_out[0] = ctx->xfer_ev_out[1] = nullptr;
     ctx->xfer_in_busy[0] = ctx->xfer_in_busy[1] = false; ctx->up_pool = nullptr;
     ctx->force_intra_group = 0; ctx->intra_waves_g4 = ctx->intra_waves_g2 = 0; ctx->last_rowgroup = 0;
+    ctx->intra_split = 0; ctx->split_epoch = 0; memset(ctx->split_tickets, 0, sizeof(ctx->split_tickets)); ctx->split_used = false; ctx->xerr_host = nullptr; ctx->last_split = 0;
     ctx->s2_dirty = ctx->st_ahead = ctx->always_sync = ctx->p_dirty = false;
     ctx->keep_coef = ctx->profiling = false; ctx->prof_mask = 0;
     poison(ctx, "icsp_debug_poisoned_context", hipErrorUnknown);

@@ -51,6 +51,9 @@
  *   ICSP_FAKE_DEVICES 2..64 (test hook, read once per process) the library presents that many devices, device d being physical device
  *                        d mod (real devices) with per-device records of its own (search tables, shared transfer streams, turns):
  *                        the multi-device paths of a host run on a one-GPU box
+ *   ICSP_INTRA_SPLIT 0|1 8-lane intra kernel, rows in pairs: 1 = every frame as TWO workgroups (upper / lower half of the block rows, handed
+ *                        out by ticket; the lower half takes the row above its first row from the upper half through tagged 8-byte
+ *                        granules in device memory), 0 = one workgroup per frame
  *   ICSP_QUANT_POW2 0|1  1 (default): quantiser steps that are both powers of two take the add / multiply / truncate form of the
  *                        quantiser in the 8-lane transform chain (oracle/fma_proof.c); 0: the multiply-high division for every step
  *   ICSP_XCD_SLICES 0..64 bands a frame is cut into when a P step's workgroups are dealt over the XCDs (0 = automatic; rounded down to a power of two)
@@ -157,6 +160,7 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
  * 8-lane form wrote the reconstruction through its LDS ring (0/1), range placed whole on one chain stream (0/1), GOP groups, block
  * rows of the 8-lane form's wavefront chained in groups of (4) or not (0).  Any pointer may be NULL.  For reports. */
 int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups, int* intra_row_group);
+int icsp_debug_last_split(icsp_ctx_t* ctx, int* split);   /* 1: the last intra luma launch ran as half-frame units (ICSP_INTRA_SPLIT) */
 /* Test hook, needs no device: a context shell in the state a failed launch-path call leaves behind (poisoned).  Every entry
  * point answers ICSP_ERR_HIP on it without touching the runtime; release it with icsp_destroy. */
 int icsp_debug_poisoned_context(icsp_ctx_t** out);

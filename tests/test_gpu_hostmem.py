@@ -298,18 +298,19 @@ def test_plain_buffer_that_starts_inside_a_registered_page_is_staged():
     ref.close()
     fsz = clip.shape[1]
     nb = n * fsz
-    raw = np.empty(((2 * nb + 4095) // 4096 + 2) * 4096, np.uint8)
-    off = (-raw.ctypes.data) % 4096
-    pages = raw[off:]
     half = 16 * 4096
-    assert capi.host_register(pages[:half])
+    span = ((half + nb + 4095) // 4096 + 1) * 4096                              # a registered head of `half` bytes + a plain buffer that starts inside it
+    raw = np.empty(2 * span + 4096, np.uint8)
+    off = (-raw.ctypes.data) % 4096
+    pa, pb = raw[off: off + span], raw[off + span: off + 2 * span]              # one such arrangement for the source, one for the target
+    assert capi.host_register(pa[:half]) and capi.host_register(pb[:half])
     try:
-        src = pages[half - 100: half - 100 + nb].reshape(n, fsz)                   # starts 100 bytes before the registration ends
+        src = pa[half - 100: half - 100 + nb].reshape(n, fsz)                      # starts 100 bytes before the registration ends
         src[:] = clip
         enc = capi.Encoder(W, H, q, q, 0, max_frames=n)
         assert enc.lib.icsp_upload(enc.ctx, capi._vp(src), 0, n) == 0
         enc.encode_resident(0, n)
-        dst = pages[half - 4000: half - 4000 + nb].reshape(n, fsz)
+        dst = pb[half - 4000: half - 4000 + nb].reshape(n, fsz)
         dst[:] = 0
         assert enc.lib.icsp_download(enc.ctx, 0, n, None, None, None, None, capi._vp(dst)) == 0
         assert np.array_equal(dst, want["recon"])
@@ -317,7 +318,7 @@ def test_plain_buffer_that_starts_inside_a_registered_page_is_staged():
         enc.close()
         _same(got, want, "straddling source: ")
     finally:
-        assert capi.host_unregister(pages[:half])
+        assert capi.host_unregister(pa[:half]) and capi.host_unregister(pb[:half])
 
 
 def test_host_warm_refuses_plain_memory():

@@ -247,3 +247,67 @@ def test_override_outside_its_range_fails_the_create(var, val):
             capi.Encoder(352, 288, 16, 16, 0, max_frames=2)
     finally:
         del os.environ[var]
+
+
+# ---- half-frame units (ICSP_INTRA_SPLIT=1, k_intra_luma8s): a frame as two workgroups, the lower half taking the row above its first
+#      row from the upper half through tagged granules in device memory
+@pytest.mark.parametrize("name,n,qdc,qac,period,w,h", [
+    ("foremanlike", 5, 16, 16, 0, 352, 288), ("mobilelike", 3, 1, 1, 0, 352, 288), ("stefanlike", 6, 8, 8, 3, 352, 288),
+    ("tablelike", 3, 8, 8, 0, 64, 48), ("newslike", 3, 16, 16, 0, 32, 32), ("mobilelike", 2, 3, 255, 0, 720, 480),
+    ("mobilelike", 2, 16, 16, 2, 32, 2304), ("tablelike", 2, 8, 8, 0, 4096, 32), ("mobilelike", 3, 2, 5, 0, 176, 144),
+    ("foremanlike", 3, 31, 2, 0, 352, 80), ("stefanlike", 2, 16, 16, 0, 352, 576), ("mobilelike", 2, 64, 64, 0, 1024, 512),
+])
+def test_half_frame_units_match_oracle(monkeypatch, name, n, qdc, qac, period, w, h):
+    monkeypatch.setenv("ICSP_INTRA_GROUP", "2")
+    monkeypatch.setenv("ICSP_INTRA_SPLIT", "1")
+    clip = clipgen.synth_clip(name, n, width=w, height=h)
+    enc = capi.Encoder(w, h, qdc, qac, period, max_frames=n)
+    got = enc.encode(clip)
+    ch, split = enc.last_choice(), enc.last_split()
+    mv, mode = enc.download_debug(0, n)
+    enc.close()
+    assert (ch["intra_lanes_per_block"], ch["intra_rows_chained"]) == (8, 2)
+    assert split == 1
+    _cmp(got, po.encode_sequence(clip, w, h, qdc, qac, period, nthreads=NT), f"{name} {w}x{h} n={n} q={qdc}/{qac} p={period}: ")
+    assert np.array_equal(mode[0], po.intra_frame(clip[0], w, h, qdc, qac, want_dbg=True)["mode"])
+
+
+def test_half_frame_units_two_rows_only_falls_back(monkeypatch):
+    """32x16: two block rows -- no pair for each half; the launch is the one-workgroup form."""
+    monkeypatch.setenv("ICSP_INTRA_GROUP", "2")
+    monkeypatch.setenv("ICSP_INTRA_SPLIT", "1")
+    clip = clipgen.synth_clip("newslike", 2, width=32, height=16)
+    enc = capi.Encoder(32, 16, 16, 16, 0, max_frames=2)
+    got = enc.encode(clip)
+    split = enc.last_split()
+    enc.close()
+    assert split == 0
+    _cmp(got, po.encode_sequence(clip, 32, 16, 16, 16, 0, nthreads=NT), "32x16: ")
+
+
+def test_half_frame_units_under_load_match_the_one_workgroup_form(monkeypatch):
+    """The hand-off under the conditions that expose a wrong protocol (uneven load, consumers whose caches have seen the lines of
+    earlier passes): two ranges of 300 + 340 frames encoded in turn, forty passes without a host wait in between, more units in a
+    launch than the chip holds at once on the larger batch; every pass's results are the one-workgroup form's, checked after the
+    last pass of each range and after the first."""
+    n0, n1 = 300, 1500
+    clip = np.concatenate([clipgen.synth_clip("foremanlike", 300), clipgen.synth_clip("mobilelike", 60)] * 5)[: n0 + n1]
+    ref = capi.Encoder(352, 288, 16, 16, 0, max_frames=n0 + n1)
+    ref.upload(clip)
+    ref.encode_resident(0, n0 + n1)
+    want = ref.download(0, n0 + n1, what=("levels", "recon", "mpm"))
+    ref.close()
+    monkeypatch.setenv("ICSP_INTRA_FORM", "8")
+    monkeypatch.setenv("ICSP_INTRA_GROUP", "2")
+    monkeypatch.setenv("ICSP_INTRA_SPLIT", "1")
+    enc = capi.Encoder(352, 288, 16, 16, 0, max_frames=n0 + n1)
+    enc.upload(clip)
+    for rep in range(40):
+        enc.encode_resident(0, n0)
+        enc.encode_resident(n0, n1)
+        if rep in (0, 39):
+            assert enc.last_split() == 1
+            got = enc.download(0, n0 + n1, what=("levels", "recon", "mpm"))
+            for k in got:
+                assert np.array_equal(got[k], want[k]), (rep, k)
+    enc.close()
