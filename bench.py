@@ -200,7 +200,7 @@ def main():
         _tj = {}
     ISSUE_PEAK = 256 * 4 * 2.4e9 / 4                     # wave-instructions/s: 256 CUs x 4 SIMDs, one per 4 cycles at 2.4 GHz
 
-    def leg_issue(leg, sec_per_pass, ranks=1):
+    def leg_issue(leg, sec_per_pass, ranks=1, choice=None):
         """What binds a loaded leg: the vector instructions of ONE pass of the leg (SQ_INSTS_VALU summed over the pass's
         launches, rocprofv3 --pmc on tools/leg_workload.py <leg>, whole batch on one GPU) over this run's time per pass, as a share
         of the chip's vector issue slots; the fp64 share; how much of their lifetime the waves spent waiting.  None without
@@ -208,6 +208,12 @@ def main():
         e = (_tj.get("legs") or {}).get(leg)
         if not e or not sec_per_pass:
             return None
+        # the counters are those of the WHOLE batch on one GPU: a shard of it runs other kernel forms at other loads, so the
+        # figure is given for one rank only, and only while this run made the choices the counted run made
+        if ranks != 1:
+            return {"skipped": "counters in profiles/traffic.json are of the whole batch on one GPU; this run shards it over %d ranks" % ranks}
+        if choice is not None and e.get("choice") and any(choice.get(k) != v for k, v in e["choice"].items()):
+            return {"skipped": "this run chose other kernel forms than the counted run", "counted_choice": e["choice"], "this_choice": choice}
         vi, f64 = e.get("valu_insts_per_pass", 0), e.get("fp64_valu_insts_per_pass", 0)
         out = {"valu_issue_frac": round(vi / ranks / sec_per_pass / ISSUE_PEAK, 4),
                "fp64_valu_frac": round(f64 / ranks * 64 / sec_per_pass / 1e9 / FP64_VALU_PEAK_GOPS, 4),
@@ -526,9 +532,9 @@ def main():
                                        "towards the latency regime of configs[2] (30 GOPs); a rank's own isolated pass is listed so that "
                                        "an N-rank line explains its efficiency"),
                    "read_roofline_frac": round(ntot / sec * (BYTES_I_FRAME_READ + 9 * BYTES_P_FRAME_READ) / 10.0 / 1e9 / HBM_PEAK_GBS / world, 5),
-                   "issue": leg_issue("config4", sec, world),
+                   "issue": leg_issue("config4", sec, world, choice4),
                    "all_intra_loaded": {"value": round(ntot / sec_i, 1), "unit": "frames/s", "ms_per_pass": round(sec_i * 1e3, 3),
-                                        "issue": leg_issue("config4_allintra", sec_i, world),
+                                        "issue": leg_issue("config4_allintra", sec_i, world, choice4i),
                                         "regime": dict(choice4i, frames_per_rank=nloc, frames_per_cu=round(nloc / 256, 2)),
                                         "read_roofline_frac": round(ntot / sec_i * BYTES_I_FRAME_READ / 1e9 / HBM_PEAK_GBS / world, 5),
                                         "rw_roofline_frac": round(ntot / sec_i * BYTES_I_FRAME_TOTAL / 1e9 / HBM_PEAK_GBS / world, 5)}}
@@ -568,7 +574,7 @@ def main():
                    "cif_equivalent_fps": round(n5 / sec5 * (w5 * h5) / P, 1), "recon_equals_oracle": bool(ok5),
                    "regime": dict(choice5, gops_per_rank=g_n, frames_per_rank=g_n * L5, macroblocks_per_p_step_per_cu=round(g_n * 8160 / 256, 1),
                                   isolated_pass_ms_this_rank=round(iso5, 2), isolated_pass_fps_this_rank=round(g_n * L5 / iso5 * 1e3, 1)),
-                   "issue": leg_issue("config5", sec5, world),
+                   "issue": leg_issue("config5", sec5, world, choice5),
                    "read_roofline_frac": round(n5 / sec5 * rd5 / 1e9 / HBM_PEAK_GBS / world, 5)}
         del gops
 
@@ -663,7 +669,10 @@ def main():
     traffic, pmc = _tj.get("k_intra_luma_bytes_per_launch"), _tj.get("k_intra_luma_sq")
     overlap = None
     try:
-        ov = json.load(open(os.path.join(ROOT, "profiles", "r04_overlap.json")))
+        import glob
+        ov_path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_overlap.json")))[-1]      # the latest round's kernel-trace summary
+        ov = json.load(open(ov_path))
+        ov["source"] = (ov.get("source") or "") + " [" + os.path.basename(ov_path) + "]"
         overlap = {k: ov[k] for k in ("launches_in_flight_median", "launch_duration_ms_median", "start_to_start_ms_median",
                                       "chip_level_GBps_from_trace", "source") if k in ov}
     except Exception:
@@ -671,6 +680,8 @@ def main():
     chip = achieved                                    # kernel's algorithmic bytes of a step / ms_per_step
     roof = {"bound": "hbm", "kernel": "k_intra_luma", "achieved": round(single_launch, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(single_launch / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "frac_is": "per launch (the contract's definition; unchanged since round 4).  Rounds 1-3 printed the chip-level figure under "
+                       "this key: that one is chip_level.frac, kept beside it every round",
             "achieved_is": "the contract's per-launch figure: algorithmic_bytes_per_launch / avg_launch_ms, the launch's own duration "
                            "under HIP events on the stream it runs on (every 4th step of the timed region).  Two such launches are in "
                            "flight at any time (two batches on two streams, profiles/r04_overlap.json), each on about half the "
@@ -712,6 +723,35 @@ def main():
             roof["valu_insts_per_launch"] = int(vi)
             roof["waiting_share_of_wave_cycles"] = pmc.get("waiting_share_of_wave_cycles")
             roof["valu_issue_peak_Ginst"] = round(peak / 1e9, 1)
+            # What binds, from the same counters: the chip issues at most `peak` vector wave-instructions a
+            # second (1024 SIMDs, one per 4 cycles at 2.4 GHz).  A frame of this leg costs the luma kernel's instructions plus its
+            # chroma kernels' (counted launches of k_chroma_dc and the strided k_residual8 of a 300-frame step, where the counter
+            # file has them; else the luma kernel's x 1.5, their measured share in round 4); of those the fp64 multiplies / adds /
+            # fused steps are what the arithmetic contract fixes -- everything else is overhead in principle.
+            kk = _tj.get("kernels") or {}
+            chroma_vi = chroma_f64 = None
+            try:
+                cd = next(v for k, v in kk.items() if k.startswith("k_chroma_dc@") and v.get("grid_threads") == 2 * NFRAMES * 256)
+                cr = next(v for k, v in kk.items() if k.startswith("k_residual8_strided@") or k == "k_residual8@%d" % (256 * 256))   # (one workgroup per CU)
+                chroma_vi = cd["SQ_INSTS_VALU"] + cr["SQ_INSTS_VALU"]
+                chroma_f64 = cd.get("fp64_valu_insts_per_launch", 0) + cr.get("fp64_valu_insts_per_launch", 0)
+            except Exception:
+                pass
+            insts_frame = (vi + chroma_vi) / NFRAMES if chroma_vi else vi * 1.5 / NFRAMES
+            f64_frame = ((ops or 0) + chroma_f64) / NFRAMES if chroma_f64 else (ops or 0) * 1.5 / NFRAMES
+            fps_gpu = fps / world
+            roof["binding"] = {
+                "resource": "valu_issue", "frac": round(insts_frame * fps_gpu / peak, 4),
+                "valu_insts_per_frame": int(insts_frame), "fp64_floor_insts_per_frame": int(f64_frame),
+                "ceiling_fps_at_current_insts": round(peak / insts_frame, 1), "ceiling_fps_at_fp64_floor": round(peak / f64_frame, 1) if f64_frame else None,
+                "value_over_ceiling_at_current_insts": round(fps_gpu * insts_frame / peak, 4),
+                "value_over_ceiling_at_fp64_floor": round(fps_gpu * f64_frame / peak, 4) if f64_frame else None,
+                "chroma_kernels": "counted" if chroma_vi else "luma kernel x 1.5 (no counted chroma launches in profiles/traffic.json)",
+                "is": "vector wave-instructions per frame of this leg (luma kernel + the step's chroma kernels, rocprofv3 SQ counters in "
+                      "profiles/traffic.json) against the chip's vector issue rate (1024 SIMDs x 2.4 GHz / 4): `frac` of the issue slots "
+                      "are filled; at today's instruction count the chip could do ceiling_fps_at_current_insts frames/s, with nothing but the "
+                      "bit-exact fp64 arithmetic left ceiling_fps_at_fp64_floor.  The HBM figures above stay the contract's; this is the "
+                      "ceiling that binds (DESIGN.md section 5)"}
     line = {
         "metric": "CIF encode fps, resident encode loop (all-intra QP=16; IPPP and the 8-GPU workloads alongside)", "value": round(fps, 1),
         "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,
@@ -733,18 +773,22 @@ def main():
                                    "reported separately (device_pack, e2e) and are part of cpu_baseline's whole-process figure"},
         "roofline": roof,
         "cpu_baseline": cpu,
+        # the oracle's C restatement on every core this process was given (a library call: no file I/O, no bitstream writing) -- the
+        # same arithmetic as the reference binary above, without its four-thread limit
+        "cpu_baseline_port": (cpu or {}).get("port_all_cores") if (cpu or {}).get("kind") == "reference" else (cpu if cpu else None),
         "parity": parity,
         "kernels_ms_per_step": {k: round(v[0], 4) for k, v in prof.items() if v[1]},
         "regime": dict(choice_ai, frames_in_flight_per_cu=round(2 * NFRAMES / 256, 2), rank0_gpu_numa_node=_node, rank0_host_thread_bound=bool(_bound.value),
                        note="two independent 300-frame batches in flight on two streams; no scaling curve over GPUs has been measured "
-                            "on hardware so far (the driver's multi-GPU node has not been available: SCALE_r01/r02 are skipped records)"),
+                            "on hardware so far (the driver's multi-GPU node has not been available: SCALE_r01..r04 are skipped records)"),
         "isolated_pass": {"ms": round(iso_ai, 4), "fps_per_gpu": round(NFRAMES / iso_ai * 1e3, 1),
                           "note": "one pass at a time, the host waiting before and after each (includes a launch and a sync round trip); in "
                                   "the timed steps consecutive passes over independent batches run side by side (DESIGN.md section 4)"},
         "psnr_y_db": round(psnr_ai, 4),
         "pcie_inclusive_fps": round(NFRAMES / pcie_dt, 1),
         "pcie_inclusive_fps_is": "the one-call boundary with the caller's arrays in pinned memory (pcie_inclusive.pinned_fps; from plain memory: "
-                                 "pageable_fps) -- never `value`",
+                                 "pageable_fps, which is what this key held until round 3 -- one call, plain memory) -- never `value`",
+        "pcie_inclusive_fps_pageable": pcie.get("pageable_fps"),
         "pcie_inclusive": pcie,
         "device_pack": {"bin_bytes": 14 + nbits // 8 + 1, "kernels_ms": round(pack_ms[0] / max(pack_ms[1], 1), 4),
                         "pack_and_copy_ms": round(pack_dt * 1e3, 3), "upload_encode_pack_fps": round(NFRAMES / e2e_dt, 1),

@@ -22,7 +22,7 @@ SYMBOLS = [
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
     "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
     "icsp_bitstream_begin", "icsp_bitstream_header", "icsp_pack_count", "icsp_pack_into", "icsp_prepare", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free", "icsp_host_register", "icsp_host_unregister", "icsp_host_warm", "icsp_copy_streams", "icsp_upload_sync",
-    "icsp_set_groups", "icsp_single_stream", "icsp_debug_poisoned_context", "icsp_debug_last_choice", "icsp_debug_last_split",
+    "icsp_set_groups", "icsp_single_stream", "icsp_debug_poisoned_context", "icsp_debug_last_choice",
     "icsp_device_pci_bus_id", "icsp_numa_node_of_pci", "icsp_device_numa_node", "icsp_numa_nodes", "icsp_numa_cpus", "icsp_parse_cpulist",
     "icsp_bind_thread_to_node", "icsp_populate_here", "icsp_chunk_device",
 ]
@@ -95,7 +95,6 @@ def load() -> C.CDLL:
         lib.icsp_set_groups.argtypes = [vp, C.c_int, C.c_int]
         lib.icsp_single_stream.argtypes = [vp, C.c_int]
         lib.icsp_debug_poisoned_context.argtypes = [C.POINTER(vp)]
-        lib.icsp_debug_last_split.argtypes = [vp, C.POINTER(C.c_int)]
         _lib = lib
     return _lib
 
@@ -357,11 +356,6 @@ class Encoder:
         self._chk(self.lib.icsp_debug_last_choice(self.ctx, *[C.byref(x) for x in v]), "icsp_debug_last_choice")
         return {"intra_lanes_per_block": v[0].value, "intra_waves_per_workgroup": v[1].value, "intra_recon_ring": bool(v[2].value),
                 "range_whole_on_one_stream": bool(v[3].value), "gop_groups": v[4].value, "intra_rows_chained": v[5].value}
-
-    def last_split(self) -> int:
-        v = C.c_int(0)
-        self._chk(self.lib.icsp_debug_last_split(self.ctx, C.byref(v)), "icsp_debug_last_split")
-        return v.value
 
     def single_stream(self, on=True):
         """Every kernel of the context on its one stream (icsp_single_stream)."""

@@ -178,11 +178,6 @@ struct DevBufs {
     int16_t* me_sums;                 // [slot][nmb][4][6] residual block sums of a P-frame MB for each search state
     int16_t* dcpred;                  // [slot][nmb][6] DC predictors
     double* coef;                     // optional [slot][nmb][6][64]
-    // half-frame units of the intra luma kernel (k_intra_luma8<.., SPLIT>): hand-off granules [slot][cols8][3], ticket counters (one per
-    // stream of the context), sticky "a wait ran out" word
-    unsigned long long* xhand;
-    unsigned* xticket;
-    int* xerr;
 };
 
 // ------------------------------------------------------------------------------------------------ wave helpers
@@ -387,21 +382,13 @@ struct icsp_ctx {
     int chroma_cap;                   // ICSP_CHROMA_CAP: KB of LDS reserved (not used) by the all-intra chroma launch of a small range placed whole
                                       // (encode_range), on top of k_residual8's 16.9 KB.  Default 60: 77 KB per workgroup -- one per CU beside up to
                                       // three 21.7 KB workgroups of the 8-lane luma kernel, two on a CU without any.  0: nothing reserved
-    bool intra_ring;                  // ICSP_INTRA_RING (default 1): the 8-lane intra kernel writes the reconstruction in 64-byte pieces through LDS
     bool single;                      // icsp_single_stream: every kernel on `stream`, no chroma stream, no group streams
     bool whole_ok;                    // ICSP_WHOLE=0: never place a range whole on one stream (comparison)
     int sticky;                       // ICSP_ERR_HIP once a call of the launch path has failed (HIPQ): the context is poisoned
     bool no_fuse;                     // ICSP_NO_FUSE=1: k_me<true> and k_frame_serial as separate launches (comparison / fallback)
-    int force_intra_nw;               // ICSP_INTRA_NW: waves per I-frame workgroup (0 = chosen from the geometry and the batch)
     int force_intra_form;             // ICSP_INTRA_FORM: 8 or 32 lanes per block in the intra luma kernel (0 = chosen from the batch)
-    int intra_split;                  // ICSP_INTRA_SPLIT: the pairs form as two workgroups per frame (1: wherever it can be built, 0: never; default: launch_intra_luma's rule)
-    unsigned split_epoch;             // tag of the last split launch's hand-off granules
-    unsigned split_tickets[4];        // tickets drawn so far from each of the four counters (0: stream, 1 / 2: group streams, 3: stream2)
-    bool split_used;                  // a split launch has been made since icsp_sync last looked at b.xerr
-    int* xerr_host;                   // pinned word for that look
-    int last_split;
-    int force_intra_group;            // ICSP_INTRA_GROUP: 8-lane form with block rows chained in groups of 4 (4), the plain wavefront (1), or chosen (0)
-    int intra_waves_g4, intra_waves_g2;   // waves of eight blocks that the widest step of the chained wavefront needs (groups of four / two rows)
+    int force_intra_group;            // ICSP_INTRA_GROUP: 8-lane form with the plain wavefront where one is built (1), rows in pairs (2), or chosen (0)
+    int intra_waves_g2;               // waves of eight blocks that the widest step of the pairs wavefront needs
     int i_groups;                     // ICSP_I_GROUPS: parts an all-intra batch of more frames than CUs is launched in (1 or 2)
     int prio_lo;
     int p_groups, prio_hi;            // GOP groups whose P-step chains run on separate streams (created on first use: a stream costs
@@ -551,23 +538,20 @@ int intra_waves_needed(const Geo& g)
 
 // the 8-lane kernel with block rows chained in groups of gc (k_intra_luma8<.., gc>): waves of eight slots that the widest step needs,
 // slots starting at a multiple of gc
-int intra_waves_chained(const Geo& g, int gc, int rows = 0)         // rows: of a part of the frame (half-frame units); 0: the whole frame
+int intra_waves_chained(const Geo& g, int gc)
 {
     int widest = 0;
-    const int rows8 = rows ? rows : g.rows8;
-    const int nsteps = g.cols8 + (rows8 - 1) + (rows8 - 1) / gc;
+    const int nsteps = g.cols8 + (g.rows8 - 1) + (g.rows8 - 1) / gc;
     for (int t = 0; t < nsteps; t++) {
         const int tp = t - (g.cols8 - 1);
         const int r_first = tp <= 0 ? 0 : gc * (tp / (gc + 1)) + std::min(tp % (gc + 1), gc);
-        const int r_last = std::min(rows8 - 1, gc * (t / (gc + 1)) + std::min(t % (gc + 1), gc - 1));
+        const int r_last = std::min(g.rows8 - 1, gc * (t / (gc + 1)) + std::min(t % (gc + 1), gc - 1));
         widest = std::max(widest, r_last - (r_first & ~(gc - 1)) + 1);
     }
     return (widest + 7) / 8;
 }
-// block rows of the upper half of a frame encoded as two units: half the rows, a whole number of pairs
-inline int split_rows(const Geo& g) { return (g.rows8 / 2) & ~1; }
 
-void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma = false, bool beside_p_steps = false);
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool beside_p_steps = false);
 
 // Orders `stream` after everything queued on the context's other streams (chroma stream, GOP-group streams): called by whatever
 // reads results, uploads, decodes, or encodes a range that partly overlaps one in flight.  No range is "in flight" afterwards.
@@ -734,7 +718,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             hipStream_t sk = chain_stream(k);
             FrameSel fk{ first + g0, L, g1 - g0 };
             // frames in flight at once (which decides the kernel form): whole placement -> another batch like this one beside it
-            LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? 2 * G : G, sk, cap_ok); });
+            LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? 2 * G : G, sk); });
         }
         const int sc_ = xcd_slices(G, cwgs);
         // A range placed whole runs beside another range's luma launch, and with up to about 1.4 frames per CU its chroma launches
@@ -793,7 +777,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         LT(ctx, ICSP_K_CHROMA_DC, scs, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, scs, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
         LT(ctx, ICSP_K_RESIDUAL, scs, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, scs, g, fs, b, 0, cwgs, sc_); });
-        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2, false, true); });
+        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2, true); });
         if (!single) {
             HIPQ(hipEventRecord(ctx->ev_join, s2));
             for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(chain_stream(k), ctx->ev_join, 0));
@@ -900,128 +884,91 @@ int decode_range(icsp_ctx* ctx, int first, int n)
 }
 
 inline size_t intra8_lds_bytes(const Geo& g, int record_rows = 2) { return (size_t)g.W + g.H + 4 * (size_t)record_rows * (g.cols8 + 2); }     // neighbour state of one frame
-// ring: the reconstruction goes out through LDS in 64-byte pieces (k_intra_luma8<.., RING>): every wavefront step has to fit one
-// round of the workgroup, and the ring (4 KB per wave) is kept to workgroups of at most eight waves
-template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, bool ring, hipStream_t st)
+// the plain wavefront (t = c8 + 2 r8): built for the frames whose widest PAIRS step does not fit eight waves -- six and eight waves
+// with the reconstruction ring (one round per step), twelve and sixteen without it (1088p: 15 waves' worth per step)
+template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
     if constexpr (NW <= 8) {
-        if (ring) {
-            const size_t lds = intra8_lds_bytes(g) + (size_t)ring_slots(NW) * 64 * kRingBlocks;
-            hipLaunchKernelGGL((k_intra_luma8<NW, true, 0>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
-            return;
-        }
-    }
-    hipLaunchKernelGGL((k_intra_luma8<NW, false, 0>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+        const size_t lds = intra8_lds_bytes(g) + (size_t)ring_slots(NW) * 64 * kRingBlocks;
+        hipLaunchKernelGGL((k_intra_luma8<NW, true, 0>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+    } else
+        hipLaunchKernelGGL((k_intra_luma8<NW, false, 0>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
 }
-// rows chained in groups of GC (always with the ring; NW covers the widest step: one round)
-template <int NW, int GC> void launch_intra8_g(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
+// rows chained in pairs (always with the ring; NW covers the widest step: one round)
+template <int NW> void launch_intra8_pairs(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
     const size_t lds = intra8_lds_bytes(g, 4) + (size_t)ring_slots_exact(NW) * 64 * kRingBlocks;
-    hipLaunchKernelGGL((k_intra_luma8<NW, true, GC>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
-}
-// the pairs form as two workgroups per frame (IntraSplit): 2 G units handed out by ticket
-template <int NW> void launch_intra8_split(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, const IntraSplit& sp, hipStream_t st)
-{
-    const size_t lds = intra8_lds_bytes(g, 4) + (size_t)ring_slots_exact(NW) * 64 * kRingBlocks;
-    hipLaunchKernelGGL((k_intra_luma8s<NW>), dim3(2 * G), dim3(NW * 64), lds, st, g, fs, b, sp);
-}
-template <int GC> void launch_intra8_chained(int nw, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
-{
-    if (nw <= 1)       launch_intra8_g<1, GC>(g, fs, b, G, st);
-    else if (nw <= 2)  launch_intra8_g<2, GC>(g, fs, b, G, st);
-    else if (nw <= 3)  launch_intra8_g<3, GC>(g, fs, b, G, st);
-    else if (nw <= 4)  launch_intra8_g<4, GC>(g, fs, b, G, st);
-    else if (nw <= 5)  launch_intra8_g<5, GC>(g, fs, b, G, st);
-    else if (nw <= 6)  launch_intra8_g<6, GC>(g, fs, b, G, st);
-    else               launch_intra8_g<8, GC>(g, fs, b, G, st);
+    hipLaunchKernelGGL((k_intra_luma8<NW, true, 2>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
 }
 
-// G: frames of this launch; G_all: frames in flight at once (other GOP groups launch theirs beside this one)
-// light_chroma: the chroma launches beside this one are encode_range's one-workgroup-per-CU form
+// Which form of the I-frame luma kernel a launch takes.  Three forms:
+//   32-lane (k_intra_luma32): two blocks per wave, as many waves as the widest wavefront step needs -- the latency form, best while
+//     every frame has a CU of its own (with more frames than CUs, capped at 8 waves x 128 VGPRs so that two workgroups share a CU);
+//   8-lane, block rows chained in PAIRS (k_intra_luma8<.., 2>): 96 steps per CIF frame instead of 114, four waves -- one per SIMD --,
+//     26 KB of LDS; from where frames share CUs, at every load;
+//   8-lane plain (k_intra_luma8<.., 0>): frames whose widest pairs step does not fit eight waves (720p, 1088p).
+// The only decision with thresholds is where the latency form ends, in frames in flight per CU (G_all / CUs) by geometry class and by
+// what runs beside the launch.  The thresholds are data: each a crossover measured by tools/sweep_regimes.py (profiles/r04_sweep.json:
+// 300 regimes x forced knobs; the default within 3 % of the best forced setting everywhere), named beside its entry.
+enum GeoClass { GEO_CIF, GEO_TALL, GEO_4CIF, GEO_WIDE };            // by the waves of two blocks the widest plain step needs (<= 16 / 17-24 / more) and the aspect
+enum Beside { BESIDE_ALONE, BESIDE_RANGE, BESIDE_P_STEPS, BESIDE_P_STEPS_MANY };   // nothing / another range's launches / P-step kernels (up to, more than 12 I frames)
+struct FormRule { int geo, pairs, beside, lat_end20; const char* measured; };     // pairs, beside: -1 = any; lat_end20: the 32-lane form up to lat_end20 / 20 frames per CU
+const FormRule kFormRules[] = {
+    { GEO_WIDE, -1, -1,                  0,  "1280x720, 1920x1088: the 32-lane form 15-28 % behind at any load (two rounds and more per step)" },
+    { GEO_4CIF,  1, BESIDE_P_STEPS,      0,  "704x576, up to 12 I frames beside P steps: pairs +3 %" },
+    { GEO_4CIF,  1, BESIDE_P_STEPS_MANY, 4,  "704x576, 13-51 I frames beside P steps: 32-lane +3 %; more: pairs +3 % (20 I frames 27.9 / 29.1 k frames/s)" },
+    { GEO_4CIF,  1, BESIDE_ALONE,        0,  "704x576, a launch on its own: pairs at any load (100 frames 0.167 / 0.173 M frames/s)" },
+    { GEO_4CIF,  1, BESIDE_RANGE,        16, "704x576, two ranges of 100 frames alternating: 0.313 M 32-lane / 0.291 M pairs; of 250: 0.48 / 0.53 M" },
+    { GEO_4CIF,  0, BESIDE_P_STEPS,      4,  "4CIF-class frames too wide for pairs, beside P steps (round 3's rule for the plain form)" },
+    { GEO_4CIF,  0, BESIDE_P_STEPS_MANY, 4,  "as above" },
+    { GEO_4CIF,  0, -1,                  16, "4CIF-class frames too wide for pairs (round 3's rule for the plain form)" },
+    { GEO_TALL, -1, BESIDE_P_STEPS,      10, "352x576 beside P steps" },
+    { GEO_TALL, -1, BESIDE_P_STEPS_MANY, 10, "as above" },
+    { GEO_TALL, -1, -1,                  20, "352x576: two ranges of 175 frames 0.62 M 32-lane / 0.76 M pairs; one frame per CU level" },
+    { GEO_CIF,  -1, BESIDE_P_STEPS,      4,  "CIF I step beside P steps: 30 GOPs 1.25 M 32-lane / 1.13 M pairs, 60 GOPs 1.42 / 1.48 M (since the slots rotate)" },
+    { GEO_CIF,  -1, BESIDE_P_STEPS_MANY, 4,  "as above (100 GOPs 1.51 / 1.54 M, 339 GOPs 1.62 / 1.66 M)" },
+    { GEO_CIF,  -1, -1,                  20, "CIF: pairs from one frame per CU on (two ranges of 150 / 300 / 3390 frames: 1.00 / 1.41 / 1.47 M 32-lane, 1.05 / 1.84 / 2.36 M pairs)" },
+};
+
+// G: frames of this launch; G_all: frames in flight at once (other GOP groups / the other range launch theirs beside this one)
 // beside_p_steps: the I step of an IPPP range -- P-step kernels of other GOP groups / ranges share the chip with this launch
-void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool light_chroma, bool beside_p_steps)
+void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const DevBufs& b, int G, int G_all, hipStream_t st, bool beside_p_steps)
 {
-    // Three forms of the I-frame luma kernel, chosen by how many frames are in flight per CU (f = G_all / CUs) and by the frame's
-    // geometry class; every threshold below is a measured crossover (tools/sweep_regimes.py -> profiles/r04_sweep.json, tools/ab_intra_g2.sh;
-    // DESIGN.md section 5 has the tables):
-    //   32-lane (k_intra_luma32): two blocks per wave, `need` waves cover the widest wavefront step -- the latency form, best while every
-    //     frame has a CU of its own (with more frames than CUs, capped at 8 waves x 128 VGPRs so that two workgroups share a CU);
-    //   8-lane with the block rows chained in PAIRS (k_intra_luma8<.., 2>): 96 steps per CIF frame instead of 114, four waves -- one per
-    //     SIMD --, 26 KB of LDS: six workgroups per CU.  From where frames share CUs, at every load (CIF, two alternating ranges of 300
-    //     frames: 1.41 M frames/s 32-lane / 1.64 M plain 8-lane / 1.84 M pairs; 3390 frames 1.47 / 2.34 / 2.36 M -- with the slots of
-    //     a step rotating over the waves; before that the plain form won above 5.5 frames per CU);
-    //   8-lane plain (k_intra_luma8<.., 0>): 21.7 KB, seven workgroups per CU -- every frame whose widest pairs step does not fit
-    //     eight waves (720p, 1088p: the 32-lane form loses 15-28 % there at any load), and ICSP_INTRA_RING=0.
-    // Where the latency form ends: CIF-class frames f = 1 (the I step of an IPPP batch, which runs beside P-step kernels: 0.2 -- 30 GOPs
-    // 1.25 M 32-lane against 1.13 M, 100 GOPs 1.51 against 1.54 M pairs); frames much taller than wide (352x576) the same (beside P steps
-    // 0.5); 4CIF-class frames (17-24 waves' worth per step: two rounds of the 32-lane form) f = 0.8 for a range placed whole beside another
-    // (two ranges of 100 frames 0.313 M 32-lane / 0.291 M pairs), while a launch on its own or beside P steps takes pairs at any load
-    // (100 frames 0.167 / 0.173 M; 20 I frames 27.9 / 29.1 k).  Without the pairs form (ICSP_INTRA_RING=0) the thresholds are those of
-    // rounds 2-3: 8-lane from 2.1 frames per CU, 1.75 beside the one-per-CU chroma launch, 1.2 beside P steps.
-    const int need = ctx->intra_waves;
-    const int need8 = (need * 2 + 7) / 8;                           // waves of eight blocks for the widest step
-    const bool wide = need > 16, wide2 = wide && need <= 24, tall = g.rows8 * 2 >= g.cols8 * 3;
-    const bool pairs_ok = ctx->intra_ring && ctx->intra_waves_g2 >= 1 && ctx->intra_waves_g2 <= 8 && !ctx->force_intra_nw;
+    const int need = ctx->intra_waves;                              // waves of two blocks for the widest plain step
+    const int need8 = (need * 2 + 7) / 8;                           // ... of eight blocks
+    const int nwp = ctx->intra_waves_g2;                            // ... of eight blocks for the widest pairs step
+    const bool pairs_ok = nwp >= 1 && nwp <= 8;
+    const int geo = need > 24 ? GEO_WIDE : need > 16 ? GEO_4CIF : (g.rows8 * 2 >= g.cols8 * 3) ? GEO_TALL : GEO_CIF;
+    const int beside = beside_p_steps ? (G_all > 12 ? BESIDE_P_STEPS_MANY : BESIDE_P_STEPS) : (G_all == G ? BESIDE_ALONE : BESIDE_RANGE);
     int form = ctx->force_intra_form;
     if (!form) {
-        int lat_end;                                                // the latency form up to lat_end / 20 frames per CU
-        if (wide && !wide2)  lat_end = 0;
-        else if (!pairs_ok)  lat_end = wide2 ? (beside_p_steps ? 4 : 16) : tall ? (beside_p_steps ? 10 : 20) : (beside_p_steps ? 24 : light_chroma ? 35 : 42);
-        else if (wide2)      lat_end = beside_p_steps ? (G_all > 12 ? 4 : 0) : G_all == G ? 0 : 16;     // (beside P steps: 13-51 I frames 32-lane +3 %, fewer or more: pairs +3 %)
-        else if (tall)       lat_end = beside_p_steps ? 10 : 20;
-        else                 lat_end = beside_p_steps ? 4 : 20;   // (since the slots rotate over the waves: 60 I frames beside P steps 1.42 M 32-lane / 1.48 M pairs, 30 level)
-        form = 20 * G_all > lat_end * ctx->n_cu ? 8 : 32;
+        int lat_end20 = 20;
+        for (const FormRule& r : kFormRules)
+            if (r.geo == geo && (r.pairs < 0 || r.pairs == (pairs_ok ? 1 : 0)) && (r.beside < 0 || r.beside == beside)) { lat_end20 = r.lat_end20; break; }
+        form = 20 * G_all > lat_end20 * ctx->n_cu ? 8 : 32;
     }
     ctx->last_rowgroup = 0;
-    // rows chained: pairs by the rule above; groups of four (87 steps, five waves: +13 % for a frame alone on its CU, slower
-    // wherever frames share CUs) only when asked for
-    // (no upper end since the slots rotate over the waves: 3390 CIF frames 2.28 M plain / 2.36 M pairs; before the rotation 2.27 / 2.17)
-    const bool auto2 = !ctx->force_intra_group && !ctx->force_intra_form && form == 8 && pairs_ok;
-    const int gc = ctx->force_intra_group == 4 ? 4 : (ctx->force_intra_group == 2 || auto2) ? 2 : 0;
-    const int nwc = gc == 4 ? ctx->intra_waves_g4 : gc == 2 ? ctx->intra_waves_g2 : 0;
-    bool chained = gc != 0;
-    if (chained && (nwc < 1 || nwc > 8 || !ctx->intra_ring || (ctx->force_intra_nw && ctx->force_intra_nw < nwc) || ctx->force_intra_form == 32)) chained = false;
-    ctx->last_split = 0;
-    if (chained && gc == 2 && ctx->intra_split == 1 && !ctx->force_intra_nw && split_rows(g) >= 2 && g.cols8 >= 2) {
-        // two units per frame (k_intra_luma8<.., SPLIT>)
-        const int hr = split_rows(g);
-        const int nw = std::max(intra_waves_chained(g, 2, hr), intra_waves_chained(g, 2, g.rows8 - hr));
-        if (nw <= 6) {
-            int tix = st == ctx->stream ? 0 : st == ctx->pstream[1] ? 1 : st == ctx->pstream[2] ? 2 : 3;
-            if (++ctx->split_epoch == 0) ctx->split_epoch = 1;      // (2^32 split launches later a stale tag could match: by then every granule of a live slot has been rewritten many times over)
-            IntraSplit sp{ hr, ctx->split_epoch, ctx->split_tickets[tix], tix };
-            ctx->split_tickets[tix] += 2u * (unsigned)G;
-            ctx->split_used = true;
-            ctx->last_form = 8; ctx->last_nw = nw; ctx->last_ring = true; ctx->last_rowgroup = 2; ctx->last_split = 1;
-            if (nw <= 2)      launch_intra8_split<2>(g, fs, b, G, sp, st);
-            else if (nw <= 3) launch_intra8_split<3>(g, fs, b, G, sp, st);
-            else if (nw <= 4) launch_intra8_split<4>(g, fs, b, G, sp, st);
-            else              launch_intra8_split<6>(g, fs, b, G, sp, st);
-            return;
-        }
-    }
-    if (chained) {
-        const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : nwc;
-        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_ring = true; ctx->last_rowgroup = gc;
-        if (gc == 4) launch_intra8_chained<4>(nw, g, fs, b, G, st); else launch_intra8_chained<2>(nw, g, fs, b, G, st);
+    if (form == 8 && pairs_ok && ctx->force_intra_group != 1) {
+        ctx->last_form = 8; ctx->last_nw = nwp; ctx->last_ring = true; ctx->last_rowgroup = 2;
+        if (nwp <= 1)       launch_intra8_pairs<1>(g, fs, b, G, st);
+        else if (nwp <= 2)  launch_intra8_pairs<2>(g, fs, b, G, st);
+        else if (nwp <= 3)  launch_intra8_pairs<3>(g, fs, b, G, st);
+        else if (nwp <= 4)  launch_intra8_pairs<4>(g, fs, b, G, st);
+        else if (nwp <= 5)  launch_intra8_pairs<5>(g, fs, b, G, st);
+        else if (nwp <= 6)  launch_intra8_pairs<6>(g, fs, b, G, st);
+        else                launch_intra8_pairs<8>(g, fs, b, G, st);
         return;
     }
     if (form == 8) {
-        const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : need8;
-        // (the template argument is >= nw, so "one round per step" holds for it when it holds for nw)
-        const bool ring = ctx->intra_ring && nw >= need8 && nw <= 8;
-        ctx->last_form = 8; ctx->last_nw = nw; ctx->last_ring = ring;
-        if (nw <= 1)       launch_intra8<1>(g, fs, b, G, ring, st);
-        else if (nw <= 2)  launch_intra8<2>(g, fs, b, G, ring, st);
-        else if (nw <= 3)  launch_intra8<3>(g, fs, b, G, ring, st);
-        else if (nw <= 4)  launch_intra8<4>(g, fs, b, G, ring, st);
-        else if (nw <= 6)  launch_intra8<6>(g, fs, b, G, ring, st);
-        else if (nw <= 8)  launch_intra8<8>(g, fs, b, G, ring, st);
-        else if (nw <= 12) launch_intra8<12>(g, fs, b, G, false, st);
-        else               launch_intra8<16>(g, fs, b, G, false, st);
+        // the plain wavefront (frames too wide for pairs; ICSP_INTRA_GROUP=1: any frame -- smaller ones leave waves of the six idle)
+        ctx->last_form = 8; ctx->last_nw = need8 <= 6 ? 6 : need8 <= 8 ? 8 : need8 <= 12 ? 12 : 16; ctx->last_ring = need8 <= 8;
+        if (need8 <= 6)       launch_intra8<6>(g, fs, b, G, st);
+        else if (need8 <= 8)  launch_intra8<8>(g, fs, b, G, st);
+        else if (need8 <= 12) launch_intra8<12>(g, fs, b, G, st);
+        else                  launch_intra8<16>(g, fs, b, G, st);
         return;
     }
-    const int nw = ctx->force_intra_nw ? ctx->force_intra_nw : (G_all > ctx->n_cu ? (need < 8 ? need : 8) : need);
+    const int nw = G_all > ctx->n_cu ? (need < 8 ? need : 8) : need;
     ctx->last_form = 32; ctx->last_nw = nw; ctx->last_ring = false;
     if (nw <= 2)       hipLaunchKernelGGL((k_intra_luma32<2, 1>), dim3(G), dim3(128), 0, st, g, fs, b);
     else if (nw <= 4)  hipLaunchKernelGGL((k_intra_luma32<4, 1>), dim3(G), dim3(256), 0, st, g, fs, b);
@@ -1437,7 +1384,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     g.mtpr = (uint32_t)(0x100000000ull / (unsigned)((g.sw + 1) / 2) + 1);
     g.fsz = (long long)g.W * g.H * 3 / 2;
     ctx->intra_waves = intra_waves_needed(g);
-    ctx->intra_waves_g4 = intra_waves_chained(g, 4); ctx->intra_waves_g2 = intra_waves_chained(g, 2);
+    ctx->intra_waves_g2 = intra_waves_chained(g, 2);
     ctx->n_cu = 256;
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ctx->n_cu = v; }
     memset(&ctx->b, 0, sizeof(ctx->b));
@@ -1453,22 +1400,19 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(ctx->flight, 0, sizeof(ctx->flight));
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
     { int v_ = 1; if (!env_int("ICSP_I_CHROMA_ON_CHAIN", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_on_chain = v_ != 0; }
-    { int v_ = 1; if (!env_int("ICSP_INTRA_RING", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->intra_ring = v_ != 0; }
     { int v_ = 60; if (!env_int("ICSP_CHROMA_CAP", 0, 120, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_cap = v_; }
     ctx->last_form = ctx->last_nw = ctx->last_ring = ctx->last_whole = ctx->last_groups = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
     int no_fuse = 0;
-    ctx->force_intra_nw = 0; ctx->force_intra_form = 0; ctx->force_intra_group = 0; ctx->last_rowgroup = 0;
-    ctx->intra_split = 0; ctx->split_epoch = 0; memset(ctx->split_tickets, 0, sizeof(ctx->split_tickets)); ctx->split_used = false; ctx->xerr_host = nullptr; ctx->last_split = 0;
-    if (!env_int("ICSP_INTRA_SPLIT", 0, 1, &ctx->intra_split)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
+    ctx->force_intra_form = 0; ctx->force_intra_group = 0; ctx->last_rowgroup = 0;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->p_groups = 2;                 // measured (300 CIF frames, period 10): 1 group 0.75 M frames/s, 2 groups 0.89 M, 3 groups -- a fourth
                                        // busy stream of the context -- 0.27 M, whatever the stream priorities and GPU_MAX_HW_QUEUES
     ctx->i_groups = 2;
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) || !env_int("ICSP_I_GROUPS", 1, 2, &ctx->i_groups) ||
-        !env_int("ICSP_INTRA_NW", 1, 16, &ctx->force_intra_nw) || !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
+        !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
         (ctx->force_intra_form != 0 && ctx->force_intra_form != 8 && ctx->force_intra_form != 32) ||
-        !env_int("ICSP_INTRA_GROUP", 0, 4, &ctx->force_intra_group) || (ctx->force_intra_group != 0 && ctx->force_intra_group != 1 && ctx->force_intra_group != 2 && ctx->force_intra_group != 4) ||
+        !env_int("ICSP_INTRA_GROUP", 0, 2, &ctx->force_intra_group) ||
         !env_int("ICSP_XCD_SLICES", 0, 64, &g_force_slices) ||
         !env_int("ICSP_SERIAL_PRIO", 0, 1, &g.prio) || !env_int("ICSP_SERIAL_BANDS", 0, 1, &g.bands)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; }
     ctx->no_fuse = no_fuse != 0;
@@ -1508,12 +1452,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ALLOC(ctx->b.me_flag, nf * sizeof(int));
     ALLOC(ctx->b.me_done, nf * sizeof(int));
     ALLOC(ctx->b.dcpred, nf * nmb * 6 * sizeof(int16_t));
-    ALLOC(ctx->b.xhand, nf * (size_t)g.cols8 * 3 * sizeof(unsigned long long));
-    ALLOC(ctx->b.xticket, 16 * sizeof(unsigned));         // four counters + the sticky error word behind them (one small block)
-    ctx->b.xerr = (int*)(ctx->b.xticket + 8);
 #undef ALLOC
-    if ((e = hipHostMalloc((void**)&ctx->xerr_host, 64, hipHostMallocDefault)) != hipSuccess) return fail(ICSP_ERR_MEM_ALLOC, "hipHostMalloc xerr", e);
-    *ctx->xerr_host = 0;
     phase("13 hipMalloc");
 #define ZERO(ptr, bytes) if ((e = hipMemsetAsync((ptr), 0, (bytes), ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipMemsetAsync " #ptr, e)
     ZERO(ctx->b.me_flag, nf * sizeof(int));            // k_me raises it, the serial kernel of the same step clears it
@@ -1522,8 +1461,6 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ZERO(ctx->b.mvd, nf * nmb * 2);
     ZERO(ctx->b.mv, nf * nmb * 2);
     ZERO(ctx->b.imode, nf * nmb * 4);
-    ZERO(ctx->b.xhand, nf * (size_t)g.cols8 * 3 * sizeof(unsigned long long));     // tag 0 is never a launch's epoch
-    ZERO(ctx->b.xticket, 16 * sizeof(unsigned));
 #undef ZERO
     phase("6 hipMemsetAsync (enqueue)");
     {   // the search tables are the same for every context: once per device and process (the call costs 7-12 ms)
@@ -1556,11 +1493,10 @@ int icsp_destroy(icsp_ctx_t* ctx)
     for (auto& e : ctx->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     void* bufs[] = { ctx->d_frames, ctx->b.recon, ctx->b.levels, ctx->b.acflag, ctx->b.mpm, ctx->b.mvd, ctx->b.mv, ctx->b.imode, ctx->b.me_ent,
-                     ctx->b.me_sums, ctx->b.me_flag, ctx->b.me_done, ctx->b.dcpred, ctx->b.coef, ctx->b.xhand, ctx->b.xticket, ctx->pk.grp_bits, ctx->pk.grp_off,
+                     ctx->b.me_sums, ctx->b.me_flag, ctx->b.me_done, ctx->b.dcpred, ctx->b.coef, ctx->pk.grp_bits, ctx->pk.grp_off,
                      ctx->pk.chunk_bits, ctx->pk.chunk_base, ctx->pk.out };
     for (void* q : bufs) if (q) (void)hipFree(q);
     if (ctx->pk_host) (void)hipHostFree(ctx->pk_host);
-    if (ctx->xerr_host) (void)hipHostFree(ctx->xerr_host);
     gop_release(ctx);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -1651,14 +1587,7 @@ int icsp_sync(icsp_ctx_t* ctx)
     ENTER(ctx);
     HIPCHK(hipSetDevice(ctx->device));
     if (int rc = join_all(ctx)) return rc;
-    if (ctx->split_used) {
-        // half-frame units: did a lower half give up waiting for its upper half (k_intra_luma8<.., SPLIT>, kSplitSpinMax)?  Its
-        // results are wrong then; the context is unusable
-        HIPCHK(hipMemcpyAsync(ctx->xerr_host, ctx->b.xerr, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        ctx->split_used = false;
-    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (*ctx->xerr_host) { ctx->err = "k_intra_luma8 (half-frame units): a wait for the upper half ran out"; ctx->sticky = ICSP_ERR_HIP; return ICSP_ERR_HIP; }
     // event pairs are read out in icsp_profile_get / icsp_profile_reset, not here: a caller timing "launch ... icsp_sync"
     // must not pay for the bookkeeping of the profiler
     return ICSP_OK;
@@ -2181,14 +2110,6 @@ int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, i
     return ICSP_OK;
 }
 
-// 1 when the last intra luma launch ran as half-frame units (k_intra_luma8s), else 0
-int icsp_debug_last_split(icsp_ctx_t* ctx, int* split)
-{
-    ENTER(ctx);
-    if (split) *split = ctx->last_split;
-    return ICSP_OK;
-}
-
 int icsp_device_pci_bus_id(int device, char* out, int cap)
 {
     if (!out || cap < 13) return ICSP_ERR_RANGE;
@@ -2309,7 +2230,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->device = 0; ctx->slot = 0; ctx->max_frames = 1;
     memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
     memset(ctx->flight, 0, sizeof(ctx->flight));
-    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true; ctx->intra_ring = true; ctx->chroma_cap = 60;
+    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true; ctx->chroma_cap = 60;
     ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;
@@ -2317,8 +2238,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->gop_stage_in_cap = ctx->gop_stage_out_cap = 0; memset(ctx->gop_ev, 0, sizeof(ctx->gop_ev)); ctx->gop_pool = nullptr;
     ctx->xfer_ev_in[0] = ctx->xfer_ev_in[1] = ctx->xfer_ev_out[0] = ctx->xfer_ev_out[1] = nullptr;
     ctx->xfer_in_busy[0] = ctx->xfer_in_busy[1] = false; ctx->up_pool = nullptr;
-    ctx->force_intra_group = 0; ctx->intra_waves_g4 = ctx->intra_waves_g2 = 0; ctx->last_rowgroup = 0;
-    ctx->intra_split = 0; ctx->split_epoch = 0; memset(ctx->split_tickets, 0, sizeof(ctx->split_tickets)); ctx->split_used = false; ctx->xerr_host = nullptr; ctx->last_split = 0;
+    ctx->force_intra_group = 0; ctx->intra_waves_g2 = 0; ctx->last_rowgroup = 0;
     ctx->s2_dirty = ctx->st_ahead = ctx->always_sync = ctx->p_dirty = false;
     ctx->keep_coef = ctx->profiling = false; ctx->prof_mask = 0;
     poison(ctx, "icsp_debug_poisoned_context", hipErrorUnknown);

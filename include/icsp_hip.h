@@ -27,17 +27,12 @@
  *   ICSP_NO_FUSE   0|1   1: a P step's four-state motion search and the per-frame serial kernel run as two launches instead of one
  *   ICSP_P_GROUPS  1..3  number of GOP groups whose P-step kernel chains run on separate streams (default 2)
  *   ICSP_I_GROUPS  1..2  parts (launches on separate streams) an all-intra batch of more frames than CUs is encoded in (default 2)
- *   ICSP_INTRA_NW  1..16 waves per workgroup of the intra luma kernel (rounded up to a built variant; default: from the
- *                        frame width and the batch size)
  *   ICSP_INTRA_FORM 8|32 lanes per 8x8 block in the intra luma kernel: 32 = latency form (two blocks per wave), 8 = throughput
- *                        form (eight blocks per wave, plain wavefront); default: by frames in flight per CU and geometry class --
- *                        32 while every frame has a CU of its own, 8 with the rows in pairs (ICSP_INTRA_GROUP) above, 8 plain
- *                        on frames too wide for pairs (profiles/r04_sweep.json)
- *   ICSP_INTRA_GROUP 0|1|2|4  8-lane intra kernel: 2 / 4 = block rows run one wavefront step apart in groups of two / four (96 / 87
- *                        steps per CIF frame instead of 114; four / five waves; frames whose widest step fits eight waves), 1 = two
- *                        steps apart throughout (plain), 0 (default) = chosen (pairs wherever the 8-lane form is, see ICSP_INTRA_FORM)
- *   ICSP_INTRA_RING 0|1  8-lane intra kernel: reconstruction written in 32-byte runs through a ring in LDS (default 1) or as 8-byte
- *                        block rows straight from the lanes (0)
+ *                        form (eight blocks per wave); default: by frames in flight per CU and geometry class -- 32 while every
+ *                        frame has a CU of its own, 8 above (the rule table kFormRules in icsp_device.hip, profiles/r04_sweep.json)
+ *   ICSP_INTRA_GROUP 0|1|2  8-lane intra kernel: 2 = block rows run one wavefront step apart in pairs (96 steps per CIF frame instead
+ *                        of 114, four waves; frames whose widest step fits eight waves), 1 = two steps apart throughout (the plain
+ *                        wavefront: what 720p / 1088p frames take anyway), 0 (default) = pairs wherever they can be built
  *   ICSP_SERIAL_PRIO 0|1 1 (default): the DC-chain waves of the per-frame serial kernel run at raised issue priority
  *   ICSP_SERIAL_BANDS 0|1 1 (default): frames taller than 512 lines run the bands of their DC chains as waves of one continued wavefront
  *   ICSP_WHOLE     0|1   0: never place a range whole on one stream when the caller alternates between independent ranges
@@ -51,9 +46,6 @@
  *   ICSP_FAKE_DEVICES 2..64 (test hook, read once per process) the library presents that many devices, device d being physical device
  *                        d mod (real devices) with per-device records of its own (search tables, shared transfer streams, turns):
  *                        the multi-device paths of a host run on a one-GPU box
- *   ICSP_INTRA_SPLIT 0|1 8-lane intra kernel, rows in pairs: 1 = every frame as TWO workgroups (upper / lower half of the block rows, handed
- *                        out by ticket; the lower half takes the row above its first row from the upper half through tagged 8-byte
- *                        granules in device memory), 0 = one workgroup per frame
  *   ICSP_QUANT_POW2 0|1  1 (default): quantiser steps that are both powers of two take the add / multiply / truncate form of the
  *                        quantiser in the 8-lane transform chain (oracle/fma_proof.c); 0: the multiply-high division for every step
  *   ICSP_XCD_SLICES 0..64 bands a frame is cut into when a P step's workgroups are dealt over the XCDs (0 = automatic; rounded down to a power of two)
@@ -160,7 +152,6 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
  * 8-lane form wrote the reconstruction through its LDS ring (0/1), range placed whole on one chain stream (0/1), GOP groups, block
  * rows of the 8-lane form's wavefront chained in groups of (4) or not (0).  Any pointer may be NULL.  For reports. */
 int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups, int* intra_row_group);
-int icsp_debug_last_split(icsp_ctx_t* ctx, int* split);   /* 1: the last intra luma launch ran as half-frame units (ICSP_INTRA_SPLIT) */
 /* Test hook, needs no device: a context shell in the state a failed launch-path call leaves behind (poisoned).  Every entry
  * point answers ICSP_ERR_HIP on it without touching the runtime; release it with icsp_destroy. */
 int icsp_debug_poisoned_context(icsp_ctx_t** out);

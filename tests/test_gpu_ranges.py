@@ -237,16 +237,17 @@ def test_chroma_reservation_never_changes_results(cap, monkeypatch):
 
 
 def test_default_scheduling_is_not_far_behind_any_forced_setting():
-    """tools/sweep_regimes.py --quick: in the headline regime (two alternating 300-frame CIF batches, all-intra and period 10) and on a
-    loaded chip (3390 frames) the library's own choices must be within 10 % of the best single forced knob (the committed sweep,
-    profiles/r04_sweep.json, holds the full table: within 3 % everywhere after round 4's fixes)."""
+    """tools/sweep_regimes.py --quick: in ten regimes -- the headline ones (two alternating 300-frame CIF batches, all-intra and period 10;
+    a loaded chip) and the closest calls of the committed sweep (profiles/r04_sweep.json: within 3 % everywhere) -- the library's own
+    choices must be within 12 % of the best forced knob.  A wall-clock comparison inside the correctness suite: the default
+    is measured before and after the forced settings, best of three runs each, and the bound is four times the sweep's worst ratio."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sweep_regimes.py"), "--quick", "--budget-s", "0.08"], stdout=subprocess.PIPE,
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "sweep_regimes.py"), "--quick", "--budget-s", "0.05"], stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     out = r.stdout.decode()
     d = json.loads(out[out.rindex("{\n \"tool\""):])
-    assert d["regimes"] == 3 and d["worst_default_over_best"] >= 0.90, out[-1500:]
+    assert d["regimes"] == 10 and d["worst_default_over_best"] >= 0.88, out[-2500:]

@@ -60,7 +60,6 @@ def test_poisoned_context_keeps_returning_hip_error():
         "icsp_set_groups": lambda: lib.icsp_set_groups(ctx, 1, 1),
         "icsp_single_stream": lambda: lib.icsp_single_stream(ctx, 1),
         "icsp_debug_last_choice": lambda: lib.icsp_debug_last_choice(ctx, None, None, None, None, None, None),
-        "icsp_debug_last_split": lambda: lib.icsp_debug_last_split(ctx, None),
         "icsp_device_view": lambda: lib.icsp_device_view(ctx, C.byref(view)),
         "icsp_debug_keep_coef": lambda: lib.icsp_debug_keep_coef(ctx, 1),
         "icsp_download_coef": lambda: lib.icsp_download_coef(ctx, 0, 1, vp),

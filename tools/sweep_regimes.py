@@ -7,11 +7,12 @@ Regimes: geometry {CIF, 352x576, 4CIF, 720p, 1088p} x batch {100 ... 3390 CIF fr
 10} x {one resident range encoded again and again, two alternating, three in rotation}.  For each regime the resident throughput
 with everything left to the library (default) and with one knob forced at a time:
 
-    all-intra: ICSP_INTRA_FORM 8 (plain wavefront) / 32, ICSP_INTRA_GROUP 2 / 4 (rows chained in pairs / fours), ICSP_CHROMA_CAP 0, ICSP_WHOLE 0 (two ranges or more), ICSP_I_GROUPS 1 (one range)
+    all-intra: ICSP_INTRA_FORM 8 (plain wavefront) / 32, ICSP_INTRA_GROUP 2 / 1 (rows chained in pairs / the plain wavefront), ICSP_CHROMA_CAP 0, ICSP_WHOLE 0 (two ranges or more), ICSP_I_GROUPS 1 (one range)
     period 10: ICSP_P_GROUPS 1 / 2, ICSP_WHOLE 0 (two ranges or more), ICSP_INTRA_FORM 8 / 32, ICSP_INTRA_GROUP 2 (the I step), ICSP_I_CHROMA_ON_CHAIN 0
 
 Every setting produces the same bytes (tests/); this is about speed only.  Writes the table and a summary (worst default / best
-ratio, the regimes below 0.97) as JSON.  --quick: three regimes (the -m gpu smoke test)."""
+ratio, the regimes below 0.97) as JSON.  --quick: ten regimes -- the headline three and the closest calls of profiles/r04_sweep.json --
+each against the knobs that came closest there, the default measured before AND after the forced settings (the -m gpu smoke test)."""
 import argparse
 import json
 import os
@@ -25,8 +26,19 @@ from icspcodec_amd import capi, clipgen  # noqa: E402
 
 GEOMS = {"CIF": (352, 288), "352x576": (352, 576), "4CIF": (704, 576), "720p": (1280, 720), "1088p": (1920, 1088)}
 BATCHES = [100, 200, 250, 270, 300, 350, 400, 600, 1000, 3390]          # CIF frames' worth of macroblocks
-KNOBS_AI = [("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_INTRA_GROUP", "4"), ("ICSP_CHROMA_CAP", "0"), ("ICSP_WHOLE", "0"), ("ICSP_I_GROUPS", "1")]
+KNOBS_AI = [("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_INTRA_GROUP", "1"), ("ICSP_CHROMA_CAP", "0"), ("ICSP_WHOLE", "0"), ("ICSP_I_GROUPS", "1")]
 KNOBS_IP = [("ICSP_P_GROUPS", "1"), ("ICSP_P_GROUPS", "2"), ("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_I_CHROMA_ON_CHAIN", "0")]
+# --quick: (geometry, batch, period, ranges, knobs to force); from profiles/r04_sweep.json's lowest default / best ratios
+QUICK = [("CIF", 300, 0, 2, [("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "1"), ("ICSP_CHROMA_CAP", "0")]),
+         ("CIF", 300, 10, 2, [("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "32")]),
+         ("CIF", 3390, 0, 1, [("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "1")]),
+         ("4CIF", 350, 10, 3, [("ICSP_INTRA_FORM", "32")]),
+         ("352x576", 100, 0, 1, [("ICSP_INTRA_FORM", "8")]),
+         ("CIF", 350, 0, 3, [("ICSP_CHROMA_CAP", "0")]),
+         ("352x576", 1000, 10, 2, [("ICSP_INTRA_FORM", "8")]),
+         ("720p", 600, 0, 2, [("ICSP_INTRA_FORM", "32")]),
+         ("CIF", 1000, 10, 2, [("ICSP_INTRA_FORM", "32"), ("ICSP_P_GROUPS", "1")]),
+         ("CIF", 270, 0, 3, [("ICSP_INTRA_FORM", "32"), ("ICSP_CHROMA_CAP", "0")])]
 _clips = {}
 
 
@@ -84,12 +96,14 @@ def main():
     ap.add_argument("--regimes", default="", help="only these: geometry:batch:period:ranges,...")
     a = ap.parse_args()
     regimes = []
+    quick_knobs = {}
     if a.regimes:
         for x in a.regimes.split(","):
             g, b, per, r = x.split(":")
             regimes.append((g, int(b), int(per), int(r)))
     elif a.quick:
-        regimes = [("CIF", 300, 0, 2), ("CIF", 300, 10, 2), ("CIF", 3390, 0, 1)]
+        regimes = [q[:4] for q in QUICK]
+        quick_knobs = {q[:4]: q[4] for q in QUICK}
     else:
         for g in a.geoms.split(","):
             for b in BATCHES:
@@ -107,13 +121,15 @@ def main():
         if n * r * (w * h * 13) > 60e9:                                 # device memory of the resident ranges
             continue
         qp = 8 if period else 16
-        knobs = [kv for kv in (KNOBS_IP if period else KNOBS_AI)
-                 if not (kv[0] == "ICSP_WHOLE" and r == 1) and not (kv[0] == "ICSP_I_GROUPS" and r > 1)]
+        knobs = quick_knobs.get((g, b, period, r)) or [kv for kv in (KNOBS_IP if period else KNOBS_AI)
+                                                        if not (kv[0] == "ICSP_WHOLE" and r == 1) and not (kv[0] == "ICSP_I_GROUPS" and r > 1)]
         try:
             dflt, choice = measure(w, h, qp, period, n, r, [], a.budget_s)
             forced = {}
             for kv in knobs:
                 forced["%s=%s" % kv], _ = measure(w, h, qp, period, n, r, [kv], a.budget_s)
+            # (the default once more behind the forced settings: as many chances as a pair of them has -- ADVICE r04)
+            dflt = max(dflt, measure(w, h, qp, period, n, r, [], a.budget_s)[0])
         except Exception as e:                                          # (a geometry / batch the box cannot hold)
             print("skip", g, b, period, r, e, flush=True)
             continue
