@@ -17,7 +17,7 @@ LIB_PATH = os.environ.get("ICSP_LIB") or os.path.join(HERE, "libicsp_hip.so")   
 # every symbol include/icsp_hip.h declares
 SYMBOLS = [
     "icsp_create", "icsp_destroy", "icsp_strerror", "icsp_device_count", "icsp_last_error", "icsp_encode_gop", "icsp_encode_gop_packed", "icsp_upload",
-    "icsp_encode_resident", "icsp_sync", "icsp_download", "icsp_device_view", "icsp_download_debug",
+    "icsp_encode_resident", "icsp_encode_resident_many", "icsp_sync", "icsp_download", "icsp_device_view", "icsp_download_debug",
     "icsp_debug_keep_coef", "icsp_download_coef", "icsp_profile_enable", "icsp_profile_reset", "icsp_profile_get",
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
     "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
@@ -65,6 +65,8 @@ def load() -> C.CDLL:
         lib.icsp_encode_gop_packed.argtypes = [vp, vp, C.c_int, vp, vp, C.c_size_t, C.POINTER(C.c_uint64)]
         lib.icsp_upload.argtypes = [vp, vp, C.c_int, C.c_int]
         lib.icsp_encode_resident.argtypes = [vp, C.c_int, C.c_int]
+        if hasattr(lib, "icsp_encode_resident_many"):         # (absent from earlier rounds' builds, which ICSP_LIB may name)
+            lib.icsp_encode_resident_many.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         lib.icsp_sync.argtypes = [vp]
         lib.icsp_download.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
         lib.icsp_device_view.argtypes = [vp, C.POINTER(DeviceView)]
@@ -289,6 +291,13 @@ class Encoder:
 
     def encode_resident(self, first, n):
         self._chk(self.lib.icsp_encode_resident(self.ctx, first, n), "icsp_encode_resident")
+
+    def encode_resident_many(self, ranges):
+        """icsp_encode_resident_many: `ranges` = [(first, n), ...], disjoint, encoded as one batch."""
+        k = len(ranges)
+        f = (C.c_int * max(k, 1))(*[int(a) for a, _ in ranges])
+        n = (C.c_int * max(k, 1))(*[int(b) for _, b in ranges])
+        self._chk(self.lib.icsp_encode_resident_many(self.ctx, k, f, n), "icsp_encode_resident_many")
 
     def sync(self):
         self._chk(self.lib.icsp_sync(self.ctx), "icsp_sync")

@@ -28,6 +28,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <unistd.h>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -167,7 +168,7 @@ struct Geo {
     double idc, iac;                  //   1 / qdc, 1 / qac (exact then)
     long long fsz;                    // bytes per frame = W*H*3/2
 };
-struct FrameSel { int first, stride, count; };     // item i -> frame slot first + i*stride
+struct FrameSel { int first, stride, count; const int* table; };     // item i -> frame slot first + i*stride, or table[i] (a coalesced list of ranges)
 struct DevBufs {
     const uint8_t* frames; uint8_t* recon;
     int16_t* levels; uint8_t* acflag; uint8_t* mpm; int8_t* mvd;
@@ -182,6 +183,8 @@ struct DevBufs {
 
 // ------------------------------------------------------------------------------------------------ wave helpers
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// frame slot of item `item` of a launch (wave-uniform: a scalar load where there is a table)
+__device__ __forceinline__ int fs_slot(const FrameSel& fs, int item) { return fs.table ? fs.table[item] : fs.first + item * fs.stride; }
 
 template <int CTRL> __device__ __forceinline__ int dpp(int v)
 {
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
     __shared__ int s_rec[2][512];
     __shared__ int16_t s_dummy;
     __shared__ int s_dummy32;
-    const int slot = fs.first + blockIdx.x * fs.stride;
+    const int slot = fs_slot(fs, (int)blockIdx.x);
     const int pl = blockIdx.y;                                 // 0 = Cb, 1 = Cr
     const int cols = g.sw, rows = g.sh, nblk = g.nmb;
     int16_t* s_sp = (int16_t*)s_dyn;                           // [nmb] block sum in, predictor out
@@ -355,7 +358,10 @@ constexpr int kMaxFlights = 4;
 //     the caller alternates between independent ranges: two whole ranges are in flight side by side instead of two halves.
 //     Calls take the two streams in turn; a range that comes back on the other stream first waits for its own previous pass
 //     (ev_done, recorded behind every whole pass), so three or more ranges in rotation load both streams evenly.
-struct Flight { int first, n; bool used, whole, done_valid; int sidx; hipEvent_t ev_done; hipEvent_t ev_p1[kMaxPGroups]; };    // ev_p1[k]: group k's first P step of the last pass over this range is done
+struct Flight { int first, n; bool used, whole, done_valid; int sidx; hipEvent_t ev_done; hipEvent_t ev_p1[kMaxPGroups];    // ev_p1[k]: group k's first P step of the last pass over this range is done
+                // a coalesced list of ranges (icsp_encode_resident_many): first / n are its hull; the list itself, and the slot tables of its
+                // launches ([step][GOP], compacted per step) on the device and in pinned host memory
+                int many_k; int* many_list; int* d_tab; int* h_tab; int tab_cap; hipEvent_t ev_tab; bool tab_up; };     // ev_tab: the tables' last upload has left h_tab
 
 } // namespace
 
@@ -614,14 +620,16 @@ int group_streams(icsp_ctx* ctx, int ng)
 //            caller must fork.  A range disjoint from everything in flight needs neither.
 //   whole: the placement this call wants (see Flight); a record of the same range with the other placement is a conflict
 //          like a partial overlap (the range's frames would change streams), resolved the same way.
-int flight_admit(icsp_ctx* ctx, int first, int n, bool allow_same, bool whole, Flight** out, bool* same, bool* joined)
+//   many: the range is the hull of a coalesced list (encode_many); a plain range and a list never count as "the same" even when
+//         their bounds are (the record then counts as an overlap).
+int flight_admit(icsp_ctx* ctx, int first, int n, bool allow_same, bool whole, Flight** out, bool* same, bool* joined, bool many = false)
 {
     *same = false; *joined = false;
     Flight* hit = nullptr;
     bool overlap = false;
     for (auto& f : ctx->flight) {
         if (!f.used) continue;
-        if (f.first == first && f.n == n) { hit = &f; continue; }
+        if (f.first == first && f.n == n && (f.many_k > 0) == many) { hit = &f; continue; }
         if (first < f.first + f.n && f.first < first + n) overlap = true;
     }
     if (hit && allow_same && !overlap && hit->whole == whole) { *same = true; *out = hit; return 0; }
@@ -632,7 +640,7 @@ int flight_admit(icsp_ctx* ctx, int first, int n, bool allow_same, bool whole, F
         *joined = true;
         slot = &ctx->flight[0];
     }
-    slot->used = true; slot->first = first; slot->n = n; slot->whole = whole; slot->sidx = 0; slot->done_valid = false;
+    slot->used = true; slot->first = first; slot->n = n; slot->whole = whole; slot->sidx = 0; slot->done_valid = false; slot->many_k = 0;
     *out = slot;
     return 0;
 }
@@ -695,7 +703,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     if (L == 1) {
         // ---- all-intra: the I frame of every GOP.  Chroma of an I frame does not depend on its luma (no pixel prediction,
         //      ENC:4347-4349), so its kernels run on a second stream beside the latency-bound luma wavefront kernel.
-        FrameSel fs{ first, L, G };
+        FrameSel fs{ first, L, G, nullptr };
         // More frames than CUs: some CUs carry two frames and finish half again as late as the others, and a launch lasts as
         // long as its slowest workgroup.  Two launches on two streams (unequal parts, so that they do not fall into step), each
         // following only what its own stream carries, keep the early finishers busy: a part starts as soon as the part before
@@ -716,7 +724,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         for (int k = 0; k < NGI; k++) {
             const int g0 = k == 0 ? 0 : 2 * G / 5, g1 = k + 1 == NGI ? G : 2 * G / 5;
             hipStream_t sk = chain_stream(k);
-            FrameSel fk{ first + g0, L, g1 - g0 };
+            FrameSel fk{ first + g0, L, g1 - g0, nullptr };
             // frames in flight at once (which decides the kernel form): whole placement -> another batch like this one beside it
             LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? 2 * G : G, sk); });
         }
@@ -766,7 +774,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     else if (same) { for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(s2, F->ev_p1[k], 0)); }
     else if (joined || !lazy || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }   // after what was queued on `stream` (uploads ...)
     {
-        FrameSel fs{ first, L, G };
+        FrameSel fs{ first, L, G, nullptr };
         // A range placed whole on one chain stream: its I frames' chroma kernels go in front of the chain instead of in front
         // of the luma kernel -- stream2 sets the pace of the alternating regime (the ranges' luma wavefront kernels, 0.22 ms of
         // latency each, follow each other there), and the chain stream has slack (ICSP_I_CHROMA_ON_CHAIN=0: as before).
@@ -795,7 +803,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             hipStream_t sk = chain_stream(k);
             if (Gi == 0) { if (i == 1) HIPQ(hipEventRecord(F->ev_p1[k], sk)); continue; }
             any = true;
-            FrameSel fs{ first + g0 * L + i, L, Gi };
+            FrameSel fs{ first + g0 * L + i, L, Gi, nullptr };
             const size_t serial_lds = serial_lds_bytes(g.nmb, g.sw, g.sh);
             // small frames: the four-state search rides in the serial kernel's launch (one kernel boundary less per step;
             // nobody waits inside that launch, see k_serial_fused); else two launches, the serial one with 1024 threads for
@@ -830,6 +838,144 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     return 0;
 }
 
+// Several disjoint resident ranges as ONE batch (icsp_encode_resident_many): every kernel of a step is launched once over the frames
+// of all ranges -- slot tables instead of arithmetic progressions (FrameSel::table) -- so that a host holding several short ranges
+// (chunks of different clips, the ends of GOP shards) gets the launches of one long range: four ranges of 150 CIF frames cost four
+// launches of 150 workgroups per pass when given one by one, one launch of 600 here.  Placement: everything on ONE of the two chain
+// streams, calls taking them in turn (the `whole` placement of encode_range), one GOP group.  Ordering against earlier calls by the
+// HULL of the list (conservative: a range of another call inside the hull counts as an overlap).
+int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
+{
+    const Geo& g = ctx->g;
+    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
+    std::vector<std::pair<int, int>> rs;
+    for (int r = 0; r < k; r++) {
+        if (int rc = check_range(ctx, firsts[r], ns[r])) return rc;
+        if (firsts[r] % L != 0) return ICSP_ERR_RANGE;
+        if (ns[r] > 0) rs.emplace_back(firsts[r], ns[r]);
+    }
+    if (rs.empty()) return 0;
+    if (rs.size() == 1 || ctx->single || ctx->always_sync) {             // (one stream / an outside consumer on it: the plain calls, in list order)
+        for (auto& r : rs) if (int rc = encode_range(ctx, r.first, r.second)) return rc;
+        return 0;
+    }
+    std::vector<std::pair<int, int>> sorted = rs;
+    std::sort(sorted.begin(), sorted.end());
+    for (size_t r = 1; r < sorted.size(); r++) if (sorted[r - 1].first + sorted[r - 1].second > sorted[r].first) return ICSP_ERR_RANGE;     // ranges must not overlap
+    const int hull_first = sorted.front().first, hull_n = sorted.back().first + sorted.back().second - hull_first;
+    // GOPs of the list, in list order; step i covers the GOPs that have a frame i
+    std::vector<int> gop_first, gop_len;
+    for (auto& r : rs) for (int f = 0; f < r.second; f += L) { gop_first.push_back(r.first + f); gop_len.push_back(std::min(L, r.second - f)); }
+    const int G = (int)gop_first.size();
+    DevBufs b = ctx->b;
+    if (!ctx->keep_coef) b.coef = nullptr;
+    if (int rc = second_stream(ctx)) return rc;
+    if (int rc = group_streams(ctx, 2)) return rc;
+    hipStream_t st = ctx->stream, s2 = ctx->stream2;
+    ctx->last_first = hull_first; ctx->last_n = hull_n; ctx->last_whole = 1; ctx->last_groups = 1;
+    Flight* F = nullptr;
+    bool same = false, joined = false;
+    if (int rc = flight_admit(ctx, hull_first, hull_n, true, true, &F, &same, &joined, true)) return rc;
+    if (same) {                                                         // the same hull: the same LIST?
+        same = F->many_k == (int)rs.size();
+        for (int r = 0; same && r < F->many_k; r++) same = F->many_list[2 * r] == rs[r].first && F->many_list[2 * r + 1] == rs[r].second;
+        if (!same) { if (int rc = join_all(ctx)) return rc; joined = true; F = &ctx->flight[0]; F->used = true; F->first = hull_first; F->n = hull_n; F->whole = true; F->sidx = 0; F->done_valid = false; }
+    }
+    if (int rc = flight_events(ctx, F, 1)) return rc;
+    if (!same) {
+        // the list and its tables: rows of G slots, row i compacted to the GOPs with a frame i (row 0: every GOP)
+        int* nl = (int*)realloc(F->many_list, sizeof(int) * 2 * rs.size());
+        if (!nl) return ICSP_ERR_MEM_ALLOC;
+        F->many_list = nl; F->many_k = (int)rs.size();
+        for (size_t r = 0; r < rs.size(); r++) { nl[2 * r] = rs[r].first; nl[2 * r + 1] = rs[r].second; }
+        const int need = L * G;
+        if (need > F->tab_cap) {
+            if (int rc = join_all(ctx)) return rc;                      // (launches of an earlier list may still read the old tables)
+            HIPCHK(hipStreamSynchronize(st));
+            if (F->d_tab) (void)hipFree(F->d_tab);
+            if (F->h_tab) (void)hipHostFree(F->h_tab);
+            F->d_tab = F->h_tab = nullptr; F->tab_cap = 0;
+            const int cap = need + need / 2 + 64;
+            if (hipMalloc((void**)&F->d_tab, sizeof(int) * cap) != hipSuccess || hipHostMalloc((void**)&F->h_tab, sizeof(int) * cap, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError(); ctx->err = "hipMalloc slot tables"; return ICSP_ERR_MEM_ALLOC;
+            }
+            F->tab_cap = cap;
+            joined = true;
+        }
+        // h_tab is about to be overwritten: its last upload must have left it (the device side is ordered by the join that every
+        // reuse of a record for another list goes through)
+        if (F->tab_up) { HIPCHK(hipEventSynchronize(F->ev_tab)); F->tab_up = false; }
+        if (!F->ev_tab) HIPCHK(hipEventCreateWithFlags(&F->ev_tab, hipEventDisableTiming));
+        for (int i = 0; i < L; i++) {
+            int c = 0;
+            for (int q = 0; q < G; q++) if (gop_len[q] > i) F->h_tab[i * G + c++] = gop_first[q] + i;
+        }
+        // up on `stream`, and every stream that launches from the tables follows (fork_all)
+        HIPCHK(hipMemcpyAsync(F->d_tab, F->h_tab, sizeof(int) * need, hipMemcpyHostToDevice, st));
+        HIPQ(hipEventRecord(F->ev_tab, st)); F->tab_up = true;
+        ctx->st_ahead = true;
+    }
+    bool moved = same && F->sidx != ctx->rr;
+    F->sidx = ctx->rr; ctx->rr ^= 1;
+    hipStream_t cs = F->sidx ? ctx->pstream[1] : st;
+    if (moved && F->done_valid) HIPQ(hipStreamWaitEvent(cs, F->ev_done, 0));
+    auto count_of = [&](int i) { int c = 0; for (int q = 0; q < G; q++) c += gop_len[q] > i; return c; };
+    const int cwgs = ((g.nmb + 3) / 4 + 3) / 4;
+    if (L == 1) {
+        FrameSel fs{ 0, 0, G, F->d_tab };
+        if (!same && (joined || ctx->st_ahead)) { if (int rc = fork_all(ctx)) return rc; }
+        LT(ctx, ICSP_K_INTRA_LUMA, cs, [&] { launch_intra_luma(ctx, g, fs, b, G, 2 * G, cs); });
+        const int sc_ = xcd_slices(G, cwgs);
+        LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
+        LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
+        ctx->s2_dirty = true;
+        if (F->sidx) ctx->p_dirty = true;
+        HIPQ(hipEventRecord(F->ev_done, cs)); F->done_valid = true;
+        return 0;
+    }
+    // IPPP: the I frames of every GOP on stream2, then one chain of P steps on the chain stream (encode_range's order of events)
+    if (same) HIPQ(hipStreamWaitEvent(s2, F->ev_p1[0], 0));
+    else if (joined || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }
+    {
+        FrameSel fs{ 0, 0, G, F->d_tab };
+        hipStream_t scs = (ctx->chroma_on_chain && G <= 32) ? cs : s2;
+        LT(ctx, ICSP_K_CHROMA_DC, scs, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, scs, g, fs, b); });
+        const int sc_ = xcd_slices(G, cwgs);
+        LT(ctx, ICSP_K_RESIDUAL, scs, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, scs, g, fs, b, 0, cwgs, sc_); });
+        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2, true); });
+        HIPQ(hipEventRecord(ctx->ev_join, s2));
+        HIPQ(hipStreamWaitEvent(cs, ctx->ev_join, 0));
+    }
+    if (F->sidx) { ctx->s2_dirty = true; ctx->p_dirty = true; } else ctx->s2_dirty = false;
+    for (int i = 1; i < L; i++) {
+        const int Gi = count_of(i);
+        if (Gi == 0) { if (i == 1) HIPQ(hipEventRecord(F->ev_p1[0], cs)); break; }
+        FrameSel fs{ 0, 0, Gi, F->d_tab + i * G };
+        const size_t serial_lds = serial_lds_bytes(g.nmb, g.sw, g.sh);
+        const bool fused = g.nmb < 2048 && !ctx->no_fuse;
+        const int tiles = ((g.sw + 1) / 2) * ((g.sh + 1) / 2);
+        const int res_wgs = ((g.nmb + 1) / 2 + (g.nmb + 3) / 4 + 3) / 4;
+        const unsigned n_serial8 = 8u * (unsigned)((Gi + 7) / 8);
+        const int st_ = xcd_slices(Gi, tiles), sr_ = xcd_slices(Gi, res_wgs);
+        int run = (int)(((long long)Gi * tiles + 4095) / 4096);
+        run = run < 1 ? 1 : (run > 32 ? 32 : run);
+        const int runs = (tiles + run - 1) / run, sf_ = xcd_slices(Gi, runs);
+        LT(ctx, ICSP_K_ME, cs, [&] {
+            hipLaunchKernelGGL((k_me<false>), xcd_grid2(Gi, tiles, st_), dim3(256), 0, cs, g, fs, b, tiles, st_, 1);
+            if (!fused) hipLaunchKernelGGL((k_me<true>), xcd_grid2(Gi, runs, sf_), dim3(256), 0, cs, g, fs, b, tiles, sf_, run);
+        });
+        LT(ctx, ICSP_K_FRAME_SERIAL, cs, [&] {
+            if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, runs, sf_)), dim3(256), serial_lds, cs, g, fs, b, (int)n_serial8, runs, sf_, run, tiles);
+            else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, cs, g, fs, b);
+        });
+        LT(ctx, ICSP_K_RESIDUAL, cs, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(Gi, res_wgs, sr_), dim3(256), 0, cs, g, fs, b, 1, res_wgs, sr_); });
+        if (i == 1) HIPQ(hipEventRecord(F->ev_p1[0], cs));
+    }
+    if (L > 1 && count_of(1) == 0) HIPQ(hipEventRecord(F->ev_p1[0], cs));
+    HIPQ(hipEventRecord(F->ev_done, cs)); F->done_valid = true;
+    return 0;
+}
+
 template <int NW> void launch_dec_luma(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
     hipLaunchKernelGGL((k_dec_intra_luma32<NW>), dim3(G), dim3(NW * 64), 0, st, g, fs, b);
@@ -855,7 +1001,7 @@ int decode_range(icsp_ctx* ctx, int first, int n)
         hipLaunchKernelGGL(k_dec_serial, dim3(n), dim3(256), (size_t)g.nmb * 16, st, g, first, n, L, b);
     });
     {
-        FrameSel fs{ first, L, G };
+        FrameSel fs{ first, L, G, nullptr };
         if (!single) { HIPQ(hipEventRecord(ctx->ev_fork, st)); HIPQ(hipStreamWaitEvent(s2, ctx->ev_fork, 0)); }
         LT(ctx, ICSP_K_DECODE, st, [&] {
             const int diag = g.rows8 < g.cols8 ? g.rows8 : g.cols8;              // widest anti-diagonal, 2 blocks per wave
@@ -876,7 +1022,7 @@ int decode_range(icsp_ctx* ctx, int first, int n)
         int Gi = 0;
         for (int gop = 0; gop < G; gop++) if (gop * L + i < n) Gi++;
         if (Gi == 0) break;
-        FrameSel fs{ first + i, L, Gi };
+        FrameSel fs{ first + i, L, Gi, nullptr };
         const long long nblk = (long long)Gi * g.nmb * 6;
         LT(ctx, ICSP_K_DECODE, st, [&] { hipLaunchKernelGGL(k_dec_blocks, dim3((unsigned)((nblk + 31) / 32)), dim3(256), 0, st, g, fs, b, 0, 6, 1); });
     }
@@ -946,6 +1092,7 @@ void launch_intra_luma(icsp_ctx* ctx, const Geo& g, const FrameSel& fs, const De
         for (const FormRule& r : kFormRules)
             if (r.geo == geo && (r.pairs < 0 || r.pairs == (pairs_ok ? 1 : 0)) && (r.beside < 0 || r.beside == beside)) { lat_end20 = r.lat_end20; break; }
         form = 20 * G_all > lat_end20 * ctx->n_cu ? 8 : 32;
+        if (ctx->force_intra_group) form = 8;                      // (asking for a wavefront of the 8-lane kernel asks for that kernel)
     }
     ctx->last_rowgroup = 0;
     if (form == 8 && pairs_ok && ctx->force_intra_group != 1) {
@@ -1500,7 +1647,14 @@ int icsp_destroy(icsp_ctx_t* ctx)
     gop_release(ctx);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    for (auto& f : ctx->flight) { if (f.ev_done) (void)hipEventDestroy(f.ev_done); for (int k = 0; k < kMaxPGroups; k++) if (f.ev_p1[k]) (void)hipEventDestroy(f.ev_p1[k]); }
+    for (auto& f : ctx->flight) {
+        if (f.ev_done) (void)hipEventDestroy(f.ev_done);
+        for (int k = 0; k < kMaxPGroups; k++) if (f.ev_p1[k]) (void)hipEventDestroy(f.ev_p1[k]);
+        if (f.ev_tab) (void)hipEventDestroy(f.ev_tab);
+        if (f.d_tab) (void)hipFree(f.d_tab);
+        if (f.h_tab) (void)hipHostFree(f.h_tab);
+        free(f.many_list);
+    }
     if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
     for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) (void)hipEventDestroy(ctx->ev_pjoin[k]); if (ctx->pstream[k]) (void)hipStreamDestroy(ctx->pstream[k]); }
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1580,6 +1734,14 @@ int icsp_encode_resident(icsp_ctx_t* ctx, int first, int n)
     if (int rc = check_range(ctx, first, n)) return rc;
     HIPCHK(hipSetDevice(ctx->device));
     return encode_range(ctx, first, n);
+}
+
+int icsp_encode_resident_many(icsp_ctx_t* ctx, int k, const int* first_frames, const int* ns)
+{
+    ENTER(ctx);
+    if (k < 0 || (k > 0 && (!first_frames || !ns))) return ICSP_ERR_UNENOUGH_PARAM;
+    HIPCHK(hipSetDevice(ctx->device));
+    return encode_many(ctx, k, first_frames, ns);
 }
 
 int icsp_sync(icsp_ctx_t* ctx)

@@ -119,6 +119,13 @@ int icsp_upload(icsp_ctx_t* ctx, const uint8_t* yuv420_in, int first_frame, int 
  * one in flight waits for everything.  Whatever reads results (icsp_sync, icsp_download, icsp_pack_*) or writes inputs
  * (icsp_upload) waits for every encode issued before it. */
 int icsp_encode_resident(icsp_ctx_t* ctx, int first_frame, int n);
+/* Several disjoint ranges as ONE batch: slots [first_frames[r], first_frames[r] + ns[r]) for r < k, each GOP aligned, none overlapping
+ * another (ICSP_ERR_RANGE otherwise).  Every kernel of a step is launched once over all ranges (slot tables instead of arithmetic
+ * progressions), so several short ranges -- chunks of different clips, the ends of GOP shards: the reference's independent GOP jobs,
+ * ICSP_thread.cpp:47-56 -- cost what one long range costs (four ranges of 150 CIF frames, all-intra: 1.0 M frames/s one by one).
+ * Same results as icsp_encode_resident on each range; asynchronous in the same way.  The same LIST encoded again follows its own previous
+ * pass; a list whose hull touches a range still in flight waits for everything. */
+int icsp_encode_resident_many(icsp_ctx_t* ctx, int k, const int* first_frames, const int* ns);
 int icsp_sync(icsp_ctx_t* ctx);
 int icsp_download(icsp_ctx_t* ctx, int first_frame, int n,
                   int16_t* levels, uint8_t* acflag, uint8_t* mpm_mode, int8_t* mvd, uint8_t* recon);

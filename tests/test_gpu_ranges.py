@@ -251,3 +251,75 @@ def test_default_scheduling_is_not_far_behind_any_forced_setting():
     out = r.stdout.decode()
     d = json.loads(out[out.rindex("{\n \"tool\""):])
     assert d["regimes"] == 10 and d["worst_default_over_best"] >= 0.88, out[-2500:]
+
+
+# ---- icsp_encode_resident_many: several disjoint ranges as ONE batch (slot tables instead of arithmetic progressions)
+@pytest.mark.parametrize("period,q,lens,gap", [(0, 16, (150, 150, 150, 150), 0), (0, 8, (37, 1, 90, 260), 5), (10, 8, (60, 43, 100, 7), 10),
+                                               (6, 16, (6, 13, 30, 1), 6), (10, 16, (300, 300), 0)])
+def test_coalesced_ranges_match_per_range_calls(period, q, lens, gap):
+    """The coalesced call against one icsp_encode_resident per range on another context, bit for bit: ragged last GOPs, a one-frame
+    range, gaps between the ranges; the same list three times without a host wait, then ANOTHER list over the same hull, then a plain
+    call on one of the ranges, then the first list again."""
+    L = max(period, 1)
+    firsts, pos = [], 0
+    for n in lens:
+        firsts.append(pos)
+        pos = (pos + n + gap + L - 1) // L * L
+    total = pos
+    src = np.concatenate([clipgen.synth_clip("stefanlike" if period else "foremanlike", 300), clipgen.synth_clip("mobilelike", 300)])
+    clip = np.concatenate([src] * (total // len(src) + 1))[:total]
+    ref = capi.Encoder(W, H, q, q, period, max_frames=total)
+    ref.upload(clip)
+    for f, n in zip(firsts, lens):
+        ref.encode_resident(f, n)
+    want = {f: ref.download(f, n) for f, n in zip(firsts, lens)}
+    ref.close()
+    enc = capi.Encoder(W, H, q, q, period, max_frames=total)
+    enc.upload(clip)
+    ranges = list(zip(firsts, lens))
+    for _ in range(3):
+        enc.encode_resident_many(ranges)
+    for f, n in ranges:
+        _cmp(enc.download(f, n), want[f], f"list x3, range {f}+{n}: ")
+    other = [ranges[0], ranges[-1]]                                   # same hull, another list (and in another order)
+    enc.encode_resident_many(other[::-1])
+    enc.encode_resident(*ranges[1])                                   # a plain call inside the hull
+    enc.encode_resident_many(ranges)
+    enc.encode_resident_many(ranges)
+    for f, n in ranges:
+        _cmp(enc.download(f, n), want[f], f"after the other list, range {f}+{n}: ")
+    enc.close()
+
+
+def test_coalesced_ranges_refuse_overlap_and_misalignment():
+    enc = capi.Encoder(W, H, 16, 16, 10, max_frames=100)
+    with pytest.raises(RuntimeError):
+        enc.encode_resident_many([(0, 30), (20, 30)])                 # overlap
+    with pytest.raises(RuntimeError):
+        enc.encode_resident_many([(0, 30), (35, 10)])                 # not GOP aligned
+    with pytest.raises(RuntimeError):
+        enc.encode_resident_many([(0, 30), (90, 20)])                 # beyond the capacity
+    enc.encode_resident_many([])                                      # nothing: fine
+    enc.encode_resident_many([(0, 0), (10, 0)])
+    enc.sync()
+    enc.close()
+
+
+def test_two_coalesced_lists_alternating_without_a_sync():
+    """Two lists of two 150-frame ranges each, in turn, forty passes without a host wait (each list whole on one of the two chain
+    streams, the tables uploaded once): the per-range results."""
+    n = 150
+    clip = np.concatenate([clipgen.synth_clip("foremanlike", 300), clipgen.synth_clip("mobilelike", 300)])
+    ref = capi.Encoder(W, H, 16, 16, 0, max_frames=600)
+    ref.upload(clip)
+    ref.encode_resident(0, 600)
+    want = ref.download(0, 600)
+    ref.close()
+    enc = capi.Encoder(W, H, 16, 16, 0, max_frames=600)
+    enc.upload(clip)
+    la, lb = [(0, n), (300, n)], [(150, n), (450, n)]
+    for _ in range(40):
+        enc.encode_resident_many(la)
+        enc.encode_resident_many(lb)
+    _cmp(enc.download(0, 600), want, "two lists alternating: ")
+    enc.close()

@@ -45,6 +45,7 @@ def test_poisoned_context_keeps_returning_hip_error():
         "icsp_upload": lambda: lib.icsp_upload(ctx, vp, 0, 1),
         "icsp_upload_sync": lambda: lib.icsp_upload_sync(ctx, vp, 0, 1),
         "icsp_encode_resident": lambda: lib.icsp_encode_resident(ctx, 0, 1),
+        "icsp_encode_resident_many": lambda: lib.icsp_encode_resident_many(ctx, 1, (C.c_int * 1)(0), (C.c_int * 1)(1)),
         "icsp_encode_gop": lambda: lib.icsp_encode_gop(ctx, vp, 1, None, None, None, None, None),
         "icsp_encode_gop_packed": lambda: lib.icsp_encode_gop_packed(ctx, vp, 1, None, vp, buf.size, C.byref(n64)),
         "icsp_download": lambda: lib.icsp_download(ctx, 0, 1, None, None, None, None, vp),
