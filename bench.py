@@ -326,6 +326,34 @@ def main():
     # resident 300-frame batch encoded again and again (the library then runs it in two parts on two streams)
     dts_same, _, (ms_same, n_same) = timed(enc, NFRAMES, a.steps, a.warmup, "k_intra_luma", alternate=False)
     choice_same = enc.last_choice()
+    # small ranges (secondary, never `value`): the same 600 resident frames as four ranges of 150, handed over
+    # one by one (A, B, C, D, A ...) and as two LISTS of two ranges in turn (icsp_encode_resident_many: one launch per list)
+    def small_ranges():
+        q = NFRAMES // 2
+        out = {}
+        for key, lists in (("one_by_one_fps", None), ("two_lists_of_two_fps", [[(0, q), (2 * q, q)], [(q, q), (3 * q, q)]])):
+            def call(k):
+                if lists:
+                    enc.encode_resident_many(lists[k & 1])
+                else:
+                    enc.encode_resident((k & 3) * q, q)
+            ncall = 200 if lists else 400
+            for k in range(40):
+                call(k)
+            enc.sync()
+            best = 0.0
+            for _ in range(3):
+                t0 = time.perf_counter()
+                for k in range(ncall):
+                    call(k)
+                enc.sync()
+                best = max(best, ncall * (2 * q if lists else q) / (time.perf_counter() - t0))
+            out[key] = round(best * world, 1)
+        out["is"] = ("four resident ranges of 150 frames (the same 600 frames as `value`): one icsp_encode_resident per range in rotation, and two "
+                     "lists of two ranges each through icsp_encode_resident_many in turn (one luma and one chroma launch per list); best of three runs")
+        return out
+    small = small_ranges()
+    enc.encode_resident(0, NFRAMES)
     enc.encode_resident(NFRAMES, NFRAMES)              # (both batches' results are checked below)
     enc.sync()
     recon = enc.download(0, NFRAMES, what=("recon",))["recon"]
@@ -790,6 +818,7 @@ def main():
                                  "pageable_fps, which is what this key held until round 3 -- one call, plain memory) -- never `value`",
         "pcie_inclusive_fps_pageable": pcie.get("pageable_fps"),
         "pcie_inclusive": pcie,
+        "small_ranges": small,
         "device_pack": {"bin_bytes": 14 + nbits // 8 + 1, "kernels_ms": round(pack_ms[0] / max(pack_ms[1], 1), 4),
                         "pack_and_copy_ms": round(pack_dt * 1e3, 3), "upload_encode_pack_fps": round(NFRAMES / e2e_dt, 1),
                         "note": "5 kernels (count, 2 scans, zero, pack) + D2H of the bits only; pcie_inclusive_fps copies "

@@ -454,22 +454,34 @@ int main(int argc, char* argv[])
             u->cv.notify_all();
         }
     };
-    // Contexts and the devices' transfer-stream pairs are made HERE, one after the other, before any worker thread runs: a stream
-    // (a hardware queue) takes 3 ms to create on an idle device and 12-55 ms while another thread's kernels or pinning calls are
-    // in flight (every queue of the process is re-mapped; `tools/trace_copy_streams.sh`), which is what the workers' concurrent
-    // set-up used to run into (3000 frames, two workers: create + copy streams 0.09-0.28 s -> see DESIGN.md section 4d).
+    // Contexts and the devices' transfer-stream pairs are made HERE, before any worker thread runs, one after the other PER DEVICE: a
+    // stream (a hardware queue) takes 3 ms to create on an idle device and 12-55 ms while another thread's kernels or pinning calls
+    // are in flight on it (every queue of the process is re-mapped; `tools/trace_copy_streams.sh`), which is what the workers'
+    // concurrent set-up used to run into (3000 frames, two workers: create + copy streams 0.09-0.28 s -> see NEGATIVE_RESULTS.md).
+    // Several devices: one creator thread per device, bound to the device's NUMA node first (the set-up would otherwise
+    // grow linearly with the devices, and the contexts' host allocations would land on the main thread's node).
     {
         const int cmax = std::min(chunk, n);
-        std::vector<bool> pair_made(ndev, false);
-        for (auto& w : workers) {
-            double t0 = now();
-            w.rc = icsp_create(&w.ctx, &params, w.device, cmax);
-            if (!w.rc) w.rc = icsp_set_groups(w.ctx, p_groups, i_groups);
-            // one chunk in all: the clip is encoded in a few milliseconds, a second stream takes longer than that to create
-            if (!w.rc && nchunks == 1) w.rc = icsp_single_stream(w.ctx, 1);
-            w.t_create = now() - t0; t0 = now();
-            if (!w.rc && shared_copies && !pair_made[w.device]) { w.rc = icsp_copy_streams(w.ctx, 1); pair_made[w.device] = true; }
-            w.t_copystreams = now() - t0;
+        auto create_for = [&](int dev) {
+            if (placement) { int bound = 0; (void)icsp_bind_thread_to_node(dev_node[dev % ndev_used], &bound); }
+            bool pair_made = false;
+            for (auto& w : workers) {
+                if (w.device != dev) continue;
+                double t0 = now();
+                w.rc = icsp_create(&w.ctx, &params, w.device, cmax);
+                if (!w.rc) w.rc = icsp_set_groups(w.ctx, p_groups, i_groups);
+                // one chunk in all: the clip is encoded in a few milliseconds, a second stream takes longer than that to create
+                if (!w.rc && nchunks == 1) w.rc = icsp_single_stream(w.ctx, 1);
+                w.t_create = now() - t0; t0 = now();
+                if (!w.rc && shared_copies && !pair_made) { w.rc = icsp_copy_streams(w.ctx, 1); pair_made = true; }
+                w.t_copystreams = now() - t0;
+            }
+        };
+        if (ndev_used <= 1) create_for(workers.empty() ? 0 : workers[0].device);
+        else {
+            std::vector<std::thread> creators;
+            for (int d = 0; d < ndev_used; d++) creators.emplace_back(create_for, d);
+            for (auto& t : creators) t.join();
         }
     }
     auto work = [&](Worker* w) {

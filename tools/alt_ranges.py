@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Resident throughput with the caller rotating over R disjoint resident ranges of n frames each (what a streaming host issues;
 bench.py's regime is R = 2): alt_ranges.py [period qp n nranges passes [width height]].  Environment (ICSP_WHOLE, ICSP_P_GROUPS, ...) is echoed.
-ICSP_ALT_MANY=1: every pass hands ALL R ranges to the library in one call (icsp_encode_resident_many) instead of one range per call."""
+ICSP_ALT_MANY=k: the R ranges form R / k lists of k ranges each; a call hands one LIST to the library (icsp_encode_resident_many), the
+calls rotate over the lists (k = R: one list again and again, every pass following the one before; k = R / 2: two lists alternating)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,28 +23,28 @@ for r in range(R):
         base = clipgen.synth_clip(name, min(n, 10), width=W, height=H, first_frame=r)
         for f in range(0, n, len(base)):
             enc.upload(base[:min(len(base), n - f)], first=r * n + f)
-MANY = os.environ.get("ICSP_ALT_MANY") == "1"
-ALL = [(r * n, n) for r in range(R)]
+MANY = int(os.environ.get("ICSP_ALT_MANY", "0"))
+LISTS = [[(r * n, n) for r in range(j, R, max(1, R // MANY))] for j in range(max(1, R // MANY))] if MANY else []
 
 
 def one(k):
     if MANY:
-        enc.encode_resident_many(ALL)
+        enc.encode_resident_many(LISTS[k % len(LISTS)])
     else:
         enc.encode_resident((k % R) * n, n)
 
 
-for k in range(100 // (R if MANY else 1) + 2):
+for k in range(100 // (MANY if MANY else 1) + 2):
     one(k)
 enc.sync()
 best = 0
 for rep in range(3):
     t0 = time.perf_counter()
-    calls = max(1, passes // R) if MANY else passes
+    calls = max(1, passes // MANY) if MANY else passes
     for k in range(calls):
         one(k)
     enc.sync()
     dt = (time.perf_counter() - t0) / calls
-    best = max(best, (n * R if MANY else n) / dt)
+    best = max(best, (n * MANY if MANY else n) / dt)
 print(f"{W}x{H} " * ((W, H) != (352, 288)) + f"period={period} qp={qp} n={n} ranges={R}: {best:10.0f} fps  ({n / best * 1e3:.4f} ms/step) env={ {k: v for k, v in os.environ.items() if k.startswith(('HIP_', 'ICSP_', 'GPU_'))} }")
 enc.close()
