@@ -620,17 +620,28 @@ int group_streams(icsp_ctx* ctx, int ng)
 //            caller must fork.  A range disjoint from everything in flight needs neither.
 //   whole: the placement this call wants (see Flight); a record of the same range with the other placement is a conflict
 //          like a partial overlap (the range's frames would change streams), resolved the same way.
-//   many: the range is the hull of a coalesced list (encode_many); a plain range and a list never count as "the same" even when
-//         their bounds are (the record then counts as an overlap).
-int flight_admit(icsp_ctx* ctx, int first, int n, bool allow_same, bool whole, Flight** out, bool* same, bool* joined, bool many = false)
+//   list (k >= 2 pairs of first, n; encode_many): first / n are then the list's hull, but overlap and identity are decided range by
+//         range -- two lists whose ranges interleave are as independent as two disjoint ranges; a plain range and a list are never
+//         "the same".
+int flight_admit(icsp_ctx* ctx, int first, int n, bool allow_same, bool whole, Flight** out, bool* same, bool* joined, int k = 0, const int* list = nullptr)
 {
     *same = false; *joined = false;
     Flight* hit = nullptr;
     bool overlap = false;
+    auto ranges_of = [](const Flight& f, int i, int& a, int& m) { if (f.many_k) { a = f.many_list[2 * i]; m = f.many_list[2 * i + 1]; } else { a = f.first; m = f.n; } };
     for (auto& f : ctx->flight) {
         if (!f.used) continue;
-        if (f.first == first && f.n == n && (f.many_k > 0) == many) { hit = &f; continue; }
-        if (first < f.first + f.n && f.first < first + n) overlap = true;
+        const int fk = f.many_k ? f.many_k : 1, nk = k ? k : 1;
+        bool equal = (f.many_k > 0) == (k > 0) && fk == nk;
+        for (int i = 0; equal && i < nk; i++) {
+            int a, m; ranges_of(f, i, a, m);
+            equal = k ? (a == list[2 * i] && m == list[2 * i + 1]) : (a == first && m == n);
+        }
+        if (equal) { hit = &f; continue; }
+        for (int i = 0; i < nk && !overlap; i++) {
+            const int a0 = k ? list[2 * i] : first, m0 = k ? list[2 * i + 1] : n;
+            for (int j = 0; j < fk && !overlap; j++) { int a, m; ranges_of(f, j, a, m); overlap = a0 < a + m && a < a0 + m0; }
+        }
     }
     if (hit && allow_same && !overlap && hit->whole == whole) { *same = true; *out = hit; return 0; }
     Flight* slot = nullptr;
@@ -842,8 +853,8 @@ int encode_range(icsp_ctx* ctx, int first, int n)
 // of all ranges -- slot tables instead of arithmetic progressions (FrameSel::table) -- so that a host holding several short ranges
 // (chunks of different clips, the ends of GOP shards) gets the launches of one long range: four ranges of 150 CIF frames cost four
 // launches of 150 workgroups per pass when given one by one, one launch of 600 here.  Placement: everything on ONE of the two chain
-// streams, calls taking them in turn (the `whole` placement of encode_range), one GOP group.  Ordering against earlier calls by the
-// HULL of the list (conservative: a range of another call inside the hull counts as an overlap).
+// streams, calls taking them in turn (the `whole` placement of encode_range), one GOP group.  Ordering against earlier calls range by
+// range (flight_admit): lists whose ranges interleave are independent of each other.
 int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
 {
     const Geo& g = ctx->g;
@@ -875,12 +886,9 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
     ctx->last_first = hull_first; ctx->last_n = hull_n; ctx->last_whole = 1; ctx->last_groups = 1;
     Flight* F = nullptr;
     bool same = false, joined = false;
-    if (int rc = flight_admit(ctx, hull_first, hull_n, true, true, &F, &same, &joined, true)) return rc;
-    if (same) {                                                         // the same hull: the same LIST?
-        same = F->many_k == (int)rs.size();
-        for (int r = 0; same && r < F->many_k; r++) same = F->many_list[2 * r] == rs[r].first && F->many_list[2 * r + 1] == rs[r].second;
-        if (!same) { if (int rc = join_all(ctx)) return rc; joined = true; F = &ctx->flight[0]; F->used = true; F->first = hull_first; F->n = hull_n; F->whole = true; F->sidx = 0; F->done_valid = false; }
-    }
+    std::vector<int> flat;
+    for (auto& r : rs) { flat.push_back(r.first); flat.push_back(r.second); }
+    if (int rc = flight_admit(ctx, hull_first, hull_n, true, true, &F, &same, &joined, (int)rs.size(), flat.data())) return rc;
     if (int rc = flight_events(ctx, F, 1)) return rc;
     if (!same) {
         // the list and its tables: rows of G slots, row i compacted to the GOPs with a frame i (row 0: every GOP)
@@ -1034,17 +1042,22 @@ inline size_t intra8_lds_bytes(const Geo& g, int record_rows = 2) { return (size
 // with the reconstruction ring (one round per step), twelve and sixteen without it (1088p: 15 waves' worth per step)
 template <int NW> void launch_intra8(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
+    // (two builds of every variant: power-of-two quantiser steps and any other steps -- blk8_chain, QM)
     if constexpr (NW <= 8) {
         const size_t lds = intra8_lds_bytes(g) + (size_t)ring_slots(NW) * 64 * kRingBlocks;
-        hipLaunchKernelGGL((k_intra_luma8<NW, true, 0>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
-    } else
-        hipLaunchKernelGGL((k_intra_luma8<NW, false, 0>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+        if (g.qpow2) hipLaunchKernelGGL((k_intra_luma8<NW, true, 0, true>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+        else         hipLaunchKernelGGL((k_intra_luma8<NW, true, 0, false>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+    } else {
+        if (g.qpow2) hipLaunchKernelGGL((k_intra_luma8<NW, false, 0, true>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+        else         hipLaunchKernelGGL((k_intra_luma8<NW, false, 0, false>), dim3(G), dim3(NW * 64), intra8_lds_bytes(g), st, g, fs, b);
+    }
 }
 // rows chained in pairs (always with the ring; NW covers the widest step: one round)
 template <int NW> void launch_intra8_pairs(const Geo& g, const FrameSel& fs, const DevBufs& b, int G, hipStream_t st)
 {
     const size_t lds = intra8_lds_bytes(g, 4) + (size_t)ring_slots_exact(NW) * 64 * kRingBlocks;
-    hipLaunchKernelGGL((k_intra_luma8<NW, true, 2>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+    if (g.qpow2) hipLaunchKernelGGL((k_intra_luma8<NW, true, 2, true>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
+    else         hipLaunchKernelGGL((k_intra_luma8<NW, true, 2, false>), dim3(G), dim3(NW * 64), lds, st, g, fs, b);
 }
 
 // Which form of the I-frame luma kernel a launch takes.  Three forms:
