@@ -34,7 +34,7 @@ KERNELS = ("k_dec_intra_luma32", "k_dec_serial", "k_dec_blocks", "k_intra_luma32
 
 
 def short(n):
-    m = re.search(r"k_intra_luma8<(\d+), (true|false), (\d+)>", n)
+    m = re.search(r"k_intra_luma8<(\d+), (true|false), (\d+)(?:, (?:true|false))?>", n)      # (round 5: a fourth argument, the quantiser form)
     if m:                                                   # the 8-lane luma kernel by variant: waves per workgroup, rows chained in groups of
         return "k_intra_luma8" + (f"_w{m.group(1)}g{m.group(3)}" if m.group(3) != "0" else "")
     for k in KERNELS:
