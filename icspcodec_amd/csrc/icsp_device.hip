@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
 // every entry point that works on a context's device state
 #define ENTER(ctx) do { if (!(ctx)) return ICSP_ERR_UNENOUGH_PARAM; if ((ctx)->sticky) return (ctx)->sticky; } while (0)
 
-struct EvPair { hipEvent_t a, b; int kernel; };
+struct EvPair { hipEvent_t a, b; int kernel; int sid; };
 constexpr int kMaxPGroups = 3;
 constexpr int kMaxFlights = 4;
 // A range of frame slots whose encode may still be running on the context's streams and has not been joined onto `stream`.
@@ -385,6 +385,8 @@ struct icsp_ctx {
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
     int last_form, last_nw, last_ring, last_whole, last_groups, last_rowgroup;     // what the last encode chose (icsp_debug_last_choice)
     bool chroma_on_chain;             // ICSP_I_CHROMA_ON_CHAIN
+    bool i_stream_b;                  // ICSP_I_STREAM_B=0: the I frames of every range on stream2 (as before round 5); default: those of a range
+                                      // placed whole on chain stream 1 on a stream of their own (pstream[2])
     int chroma_cap;                   // ICSP_CHROMA_CAP: KB of LDS reserved (not used) by the all-intra chroma launch of a small range placed whole
                                       // (encode_range), on top of k_residual8's 16.9 KB.  Default 60: 77 KB per workgroup -- one per CU beside up to
                                       // three 21.7 KB workgroups of the 8-lane luma kernel, two on a CU without any.  0: nothing reserved
@@ -423,6 +425,7 @@ struct icsp_ctx {
     bool keep_coef, profiling;
     unsigned prof_mask;               // which kernels get HIP events (icsp_profile_enable's argument, bit k = kernel k)
     std::vector<EvPair> ev_pending;
+    FILE* tl_file; hipEvent_t tl_base;    // ICSP_TIMELINE_DUMP=<file> (diagnostics): every launch's start / end against one base event, written at every collect
     std::vector<EvPair> ev_pool;
     double prof_ms[ICSP_K_COUNT];
     long long prof_n[ICSP_K_COUNT];
@@ -499,6 +502,7 @@ template <typename F> int launch_timed(icsp_ctx* ctx, int kernel, hipStream_t st
         if (hipEventCreate(&e.b) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(e.a); f(); HIPQ(hipGetLastError()); return 0; }
     }
     e.kernel = kernel;
+    e.sid = st == ctx->stream ? 0 : st == ctx->stream2 ? 1 : st == ctx->pstream[1] ? 2 : st == ctx->pstream[2] ? 3 : 4;
     const hipError_t ea = hipEventRecord(e.a, st);
     f();
     const hipError_t el = hipGetLastError();
@@ -516,6 +520,8 @@ int collect_profile(icsp_ctx* ctx)
         float ms = 0;
         if (hipEventSynchronize(e.b) == hipSuccess && hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
             ctx->prof_ms[e.kernel] += ms; ctx->prof_n[e.kernel] += 1;
+            float t0 = 0;
+            if (ctx->tl_file && hipEventElapsedTime(&t0, ctx->tl_base, e.a) == hipSuccess) fprintf(ctx->tl_file, "%d %d %.1f %.1f\n", e.kernel, e.sid, t0 * 1e3, (t0 + ms) * 1e3);
         } else (void)hipGetLastError();
         ctx->ev_pool.push_back(e);
     }
@@ -664,6 +670,37 @@ int flight_events(icsp_ctx* ctx, Flight* f, int ng)
     return 0;
 }
 
+// The three launches of one P step over the frames `fs` selects (the i-th frame of every GOP of a chain) on stream sk.
+int launch_p_step(icsp_ctx* ctx, const DevBufs& b, const FrameSel& fs, hipStream_t sk)
+{
+    const Geo& g = ctx->g;
+    const int Gi = fs.count;
+    const size_t serial_lds = serial_lds_bytes(g.nmb, g.sw, g.sh);
+    // small frames: the four-state search rides in the serial kernel's launch (one kernel boundary less per step;
+    // nobody waits inside that launch, see k_serial_fused); else two launches, the serial one with 1024 threads for
+    // its staging loops
+    const bool fused = g.nmb < 2048 && !ctx->no_fuse;
+    const int tiles = ((g.sw + 1) / 2) * ((g.sh + 1) / 2);      // 2x2 macroblock tiles, one search workgroup each
+    const int res_wgs = ((g.nmb + 1) / 2 + (g.nmb + 3) / 4 + 3) / 4;     // k_residual8 workgroups per frame: luma + chroma waves
+    const unsigned n_serial8 = 8u * (unsigned)((Gi + 7) / 8);
+    const int st_ = xcd_slices(Gi, tiles), sr_ = xcd_slices(Gi, res_wgs);
+    // four-state search: a run of tiles per workgroup once one-per-tile would mean more than about 4096 workgroups,
+    // which in the usual case (no flag up) do nothing but get dispatched
+    int run = (int)(((long long)Gi * tiles + 4095) / 4096);
+    run = run < 1 ? 1 : (run > 32 ? 32 : run);
+    const int runs = (tiles + run - 1) / run, sf_ = xcd_slices(Gi, runs);
+    LT(ctx, ICSP_K_ME, sk, [&] {
+        hipLaunchKernelGGL((k_me<false>), xcd_grid2(Gi, tiles, st_), dim3(256), 0, sk, g, fs, b, tiles, st_, 1);
+        if (!fused) hipLaunchKernelGGL((k_me<true>), xcd_grid2(Gi, runs, sf_), dim3(256), 0, sk, g, fs, b, tiles, sf_, run);
+    });
+    LT(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
+        if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, runs, sf_)), dim3(256), serial_lds, sk, g, fs, b, (int)n_serial8, runs, sf_, run, tiles);
+        else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
+    });
+    LT(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(Gi, res_wgs, sr_), dim3(256), 0, sk, g, fs, b, 1, res_wgs, sr_); });
+    return 0;
+}
+
 int encode_range(icsp_ctx* ctx, int first, int n)
 {
     const Geo& g = ctx->g;
@@ -778,9 +815,12 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // them only).  So the I frames of the next pass, a latency-bound launch on a few CUs, run beside P steps 2.. of this one
     // -- or beside another range's P steps -- instead of in front of an idle chip.
     if (int rc = group_streams(ctx, NG)) return rc;
-    // (The I frames of two alternating ranges, latency-bound launches on a few CUs each, follow each other on stream2 and set
-    //  the pace of that regime.  Giving every other range's I frames a stream of their own -- a fourth busy stream of the
-    //  context -- was measured: 1.05 M -> 0.86 M frames/s, with GPU_MAX_HW_QUEUES=8 as well; see DESIGN.md, negative results.)
+    // The I frames of two alternating ranges are latency-bound launches on a few CUs each (0.22 ms for 30 CIF frames); following each
+    // other on stream2 they set the pace of that regime (0.43 ms per round of two ranges).  So those of a range placed whole on
+    // chain stream 1 get a stream of their own (pstream[2]): two ranges of 30 GOPs alternating 1.235 -> 1.37 M frames/s, three in
+    // rotation 1.19 -> 1.32 M, two of 15 GOPs 0.65 -> 0.97 M, two of 60 GOPs +1 % (profiles/r05_exp_istream.txt; ICSP_I_STREAM_B=0:
+    // as before.  Round 3 measured the same idea as a loss, 1.05 -> 0.86 M, when the chroma kernels still rode on stream2.)
+    if (whole && ctx->i_stream_b && F->sidx) { if (int rc = group_streams(ctx, 3)) return rc; s2 = ctx->pstream[2]; }
     if (single) { /* one stream: stream order is the order */ }
     else if (same) { for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(s2, F->ev_p1[k], 0)); }
     else if (joined || !lazy || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }   // after what was queued on `stream` (uploads ...)
@@ -805,44 +845,26 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // every chain is ordered after stream2's work; `stream` itself is one of them unless the range went whole onto the group stream
     if (whole && F->sidx) ctx->s2_dirty = true; else ctx->s2_dirty = false;
     if (NG > 1 || (whole && F->sidx)) ctx->p_dirty = true;
+    // P step i of GOP group k on stream sk; -1: no GOP of the group has a frame i
+    auto p_step = [&](int k, int i, hipStream_t sk) -> int {
+        const int g0 = group_lo(k), g1 = group_lo(k + 1);
+        int Gi = 0;
+        for (int gop = g0; gop < g1; gop++) if (gop * L + i < n) Gi++;
+        if (Gi == 0) return -1;
+        FrameSel fs{ first + g0 * L + i, L, Gi, nullptr };
+        return launch_p_step(ctx, b, fs, sk);
+    };
     for (int i = 1; i < L; i++) {
         bool any = false;
         for (int k = 0; k < NG; k++) {
-            const int g0 = group_lo(k), g1 = group_lo(k + 1);
-            int Gi = 0;
-            for (int gop = g0; gop < g1; gop++) if (gop * L + i < n) Gi++;
             hipStream_t sk = chain_stream(k);
-            if (Gi == 0) { if (i == 1) HIPQ(hipEventRecord(F->ev_p1[k], sk)); continue; }
-            any = true;
-            FrameSel fs{ first + g0 * L + i, L, Gi, nullptr };
-            const size_t serial_lds = serial_lds_bytes(g.nmb, g.sw, g.sh);
-            // small frames: the four-state search rides in the serial kernel's launch (one kernel boundary less per step;
-            // nobody waits inside that launch, see k_serial_fused); else two launches, the serial one with 1024 threads for
-            // its staging loops
-            const bool fused = g.nmb < 2048 && !ctx->no_fuse;
-            const int tiles = ((g.sw + 1) / 2) * ((g.sh + 1) / 2);      // 2x2 macroblock tiles, one search workgroup each
-            const int res_wgs = ((g.nmb + 1) / 2 + (g.nmb + 3) / 4 + 3) / 4;     // k_residual8 workgroups per frame: luma + chroma waves
-            const unsigned n_serial8 = 8u * (unsigned)((Gi + 7) / 8);
-            const int st_ = xcd_slices(Gi, tiles), sr_ = xcd_slices(Gi, res_wgs);
-            // four-state search: a run of tiles per workgroup once one-per-tile would mean more than about 4096 workgroups,
-            // which in the usual case (no flag up) do nothing but get dispatched
-            int run = (int)(((long long)Gi * tiles + 4095) / 4096);
-            run = run < 1 ? 1 : (run > 32 ? 32 : run);
-            const int runs = (tiles + run - 1) / run, sf_ = xcd_slices(Gi, runs);
-            LT(ctx, ICSP_K_ME, sk, [&] {
-                hipLaunchKernelGGL((k_me<false>), xcd_grid2(Gi, tiles, st_), dim3(256), 0, sk, g, fs, b, tiles, st_, 1);
-                if (!fused) hipLaunchKernelGGL((k_me<true>), xcd_grid2(Gi, runs, sf_), dim3(256), 0, sk, g, fs, b, tiles, sf_, run);
-            });
-            LT(ctx, ICSP_K_FRAME_SERIAL, sk, [&] {
-                if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, runs, sf_)), dim3(256), serial_lds, sk, g, fs, b, (int)n_serial8, runs, sf_, run, tiles);
-                else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, sk, g, fs, b);
-            });
-            LT(ctx, ICSP_K_RESIDUAL, sk, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(Gi, res_wgs, sr_), dim3(256), 0, sk, g, fs, b, 1, res_wgs, sr_); });
+            const int rc = p_step(k, i, sk);
+            if (rc > 0) return rc;
+            any = any || rc == 0;
             if (i == 1) HIPQ(hipEventRecord(F->ev_p1[k], sk));             // the I frames of the next pass over this range may start
         }
         if (!any) break;
     }
-    if (L > 1 && n <= 1) { for (int k = 0; k < NG; k++) HIPQ(hipEventRecord(F->ev_p1[k], chain_stream(k))); }   // (no P step at all)
     if (whole) { HIPQ(hipEventRecord(F->ev_done, chain_stream(0))); F->done_valid = true; }
     // a zero-copy consumer on `stream` (icsp_device_view) must find every group's results ordered before it
     if (!lazy) { if (int rc = join_all(ctx)) return rc; }
@@ -941,7 +963,8 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
         HIPQ(hipEventRecord(F->ev_done, cs)); F->done_valid = true;
         return 0;
     }
-    // IPPP: the I frames of every GOP on stream2, then one chain of P steps on the chain stream (encode_range's order of events)
+    // IPPP: the I frames of every GOP on stream2 (or the second I stream), then one chain of P steps on the chain stream (encode_range's order of events)
+    if (ctx->i_stream_b && F->sidx) { if (int rc = group_streams(ctx, 3)) return rc; s2 = ctx->pstream[2]; }
     if (same) HIPQ(hipStreamWaitEvent(s2, F->ev_p1[0], 0));
     else if (joined || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }
     {
@@ -955,31 +978,18 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
         HIPQ(hipStreamWaitEvent(cs, ctx->ev_join, 0));
     }
     if (F->sidx) { ctx->s2_dirty = true; ctx->p_dirty = true; } else ctx->s2_dirty = false;
-    for (int i = 1; i < L; i++) {
+    auto p_step = [&](int i, hipStream_t sk) -> int {               // -1: no GOP of the list has a frame i
         const int Gi = count_of(i);
-        if (Gi == 0) { if (i == 1) HIPQ(hipEventRecord(F->ev_p1[0], cs)); break; }
+        if (Gi == 0) return -1;
         FrameSel fs{ 0, 0, Gi, F->d_tab + i * G };
-        const size_t serial_lds = serial_lds_bytes(g.nmb, g.sw, g.sh);
-        const bool fused = g.nmb < 2048 && !ctx->no_fuse;
-        const int tiles = ((g.sw + 1) / 2) * ((g.sh + 1) / 2);
-        const int res_wgs = ((g.nmb + 1) / 2 + (g.nmb + 3) / 4 + 3) / 4;
-        const unsigned n_serial8 = 8u * (unsigned)((Gi + 7) / 8);
-        const int st_ = xcd_slices(Gi, tiles), sr_ = xcd_slices(Gi, res_wgs);
-        int run = (int)(((long long)Gi * tiles + 4095) / 4096);
-        run = run < 1 ? 1 : (run > 32 ? 32 : run);
-        const int runs = (tiles + run - 1) / run, sf_ = xcd_slices(Gi, runs);
-        LT(ctx, ICSP_K_ME, cs, [&] {
-            hipLaunchKernelGGL((k_me<false>), xcd_grid2(Gi, tiles, st_), dim3(256), 0, cs, g, fs, b, tiles, st_, 1);
-            if (!fused) hipLaunchKernelGGL((k_me<true>), xcd_grid2(Gi, runs, sf_), dim3(256), 0, cs, g, fs, b, tiles, sf_, run);
-        });
-        LT(ctx, ICSP_K_FRAME_SERIAL, cs, [&] {
-            if (fused) hipLaunchKernelGGL(k_serial_fused, dim3(n_serial8 + xcd_grid(Gi, runs, sf_)), dim3(256), serial_lds, cs, g, fs, b, (int)n_serial8, runs, sf_, run, tiles);
-            else hipLaunchKernelGGL(k_frame_serial, dim3(Gi), dim3(g.nmb >= 2048 ? 1024 : 256), serial_lds, cs, g, fs, b);
-        });
-        LT(ctx, ICSP_K_RESIDUAL, cs, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(Gi, res_wgs, sr_), dim3(256), 0, cs, g, fs, b, 1, res_wgs, sr_); });
-        if (i == 1) HIPQ(hipEventRecord(F->ev_p1[0], cs));
+        return launch_p_step(ctx, b, fs, sk);
+    };
+    for (int i = 1; i < L; i++) {
+        const int rc = p_step(i, cs);
+        if (rc > 0) return rc;
+        if (i == 1) HIPQ(hipEventRecord(F->ev_p1[0], cs));              // the I frames of the next pass over this list may start
+        if (rc < 0) break;
     }
-    if (L > 1 && count_of(1) == 0) HIPQ(hipEventRecord(F->ev_p1[0], cs));
     HIPQ(hipEventRecord(F->ev_done, cs)); F->done_valid = true;
     return 0;
 }
@@ -1081,9 +1091,10 @@ const FormRule kFormRules[] = {
     { GEO_4CIF,  0, BESIDE_P_STEPS,      4,  "4CIF-class frames too wide for pairs, beside P steps (round 3's rule for the plain form)" },
     { GEO_4CIF,  0, BESIDE_P_STEPS_MANY, 4,  "as above" },
     { GEO_4CIF,  0, -1,                  16, "4CIF-class frames too wide for pairs (round 3's rule for the plain form)" },
-    { GEO_TALL, -1, BESIDE_P_STEPS,      10, "352x576 beside P steps" },
-    { GEO_TALL, -1, BESIDE_P_STEPS_MANY, 10, "as above" },
-    { GEO_TALL, -1, -1,                  20, "352x576: two ranges of 175 frames 0.62 M 32-lane / 0.76 M pairs; one frame per CU level" },
+    { GEO_TALL, -1, BESIDE_P_STEPS,      0,  "352x576, up to 12 I frames beside P steps: pairs +2-4 % (5 / 10 / 12 I frames, one to three ranges: profiles/r05_sweep_cif_tall.json)" },
+    { GEO_TALL, -1, BESIDE_P_STEPS_MANY, 2,  "352x576, 13-25 I frames beside P steps: 32-lane +1-5 % (17 / 20 I frames); 30 / 50 I frames: pairs +2-5 %" },
+    { GEO_TALL, -1, BESIDE_ALONE,        0,  "352x576, a launch on its own: pairs (50 frames +5.6 %, 100-150 +1 %, 175-200 -1.3 %, 300 and more +20 %)" },
+    { GEO_TALL, -1, BESIDE_RANGE,        20, "352x576: two ranges of 125 frames 0.66 M 32-lane / 0.59 M pairs, of 175 frames 0.62 / 0.79 M; one frame per CU level" },
     { GEO_CIF,  -1, BESIDE_P_STEPS,      4,  "CIF I step beside P steps: 30 GOPs 1.25 M 32-lane / 1.13 M pairs, 60 GOPs 1.42 / 1.48 M (since the slots rotate)" },
     { GEO_CIF,  -1, BESIDE_P_STEPS_MANY, 4,  "as above (100 GOPs 1.51 / 1.54 M, 339 GOPs 1.62 / 1.66 M)" },
     { GEO_CIF,  -1, -1,                  20, "CIF: pairs from one frame per CU on (two ranges of 150 / 300 / 3390 frames: 1.00 / 1.41 / 1.47 M 32-lane, 1.05 / 1.84 / 2.36 M pairs)" },
@@ -1528,6 +1539,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->p = *p; ctx->device = device_id; ctx->slot = slot_id; ctx->max_frames = max_frames;
     ctx->keep_coef = false; ctx->profiling = false; ctx->prof_mask = 0;
     memset(ctx->prof_ms, 0, sizeof(ctx->prof_ms)); memset(ctx->prof_n, 0, sizeof(ctx->prof_n));
+    ctx->tl_file = nullptr; ctx->tl_base = nullptr;
     Geo& g = ctx->g;
     g.W = p->width; g.H = p->height; g.sw = g.W / 16; g.sh = g.H / 16; g.nmb = g.sw * g.sh;
     g.cols8 = 2 * g.sw; g.rows8 = 2 * g.sh; g.cw = g.W / 2; g.ch = g.H / 2;
@@ -1560,6 +1572,7 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(ctx->flight, 0, sizeof(ctx->flight));
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
     { int v_ = 1; if (!env_int("ICSP_I_CHROMA_ON_CHAIN", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_on_chain = v_ != 0; }
+    { int v_ = 1; if (!env_int("ICSP_I_STREAM_B", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->i_stream_b = v_ != 0; }
     { int v_ = 60; if (!env_int("ICSP_CHROMA_CAP", 0, 120, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_cap = v_; }
     ctx->last_form = ctx->last_nw = ctx->last_ring = ctx->last_whole = ctx->last_groups = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
@@ -1638,6 +1651,22 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     phase("search tables + their sync");
     if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamSynchronize", e);
     phase("final sync");
+    if (const char* tl = getenv("ICSP_TIMELINE_DUMP")) {
+        // diagnostics: every launch between HIP events, "kernel stream start_us end_us" against one base event (tools/timeline_events.py);
+        // the host pays two event records per launch
+        ctx->tl_file = fopen(tl, "a");
+        if (ctx->tl_file && hipEventCreate(&ctx->tl_base) == hipSuccess && hipEventRecord(ctx->tl_base, ctx->stream) == hipSuccess) {
+            ctx->profiling = true; ctx->prof_mask = 0xffffffffu;
+            for (int i = 0; i < 6000; i++) {
+                EvPair ep;
+                if (hipEventCreate(&ep.a) != hipSuccess) break;
+                if (hipEventCreate(&ep.b) != hipSuccess) { (void)hipEventDestroy(ep.a); break; }
+                ep.kernel = 0; ep.sid = 0;
+                ctx->ev_pool.push_back(ep);
+            }
+        }
+        (void)hipGetLastError();
+    }
     *out = ctx;
     return ICSP_OK;
 }
@@ -1650,6 +1679,8 @@ int icsp_destroy(icsp_ctx_t* ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->stream2) (void)hipStreamSynchronize(ctx->stream2);
     for (int k = 1; k < kMaxPGroups; k++) if (ctx->pstream[k]) (void)hipStreamSynchronize(ctx->pstream[k]);
+    if (ctx->tl_file) { collect_profile(ctx); fclose(ctx->tl_file); ctx->tl_file = nullptr; }
+    if (ctx->tl_base) (void)hipEventDestroy(ctx->tl_base);
     for (auto& e : ctx->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : ctx->ev_pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     void* bufs[] = { ctx->d_frames, ctx->b.recon, ctx->b.levels, ctx->b.acflag, ctx->b.mpm, ctx->b.mvd, ctx->b.mv, ctx->b.imode, ctx->b.me_ent,
@@ -2405,7 +2436,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->device = 0; ctx->slot = 0; ctx->max_frames = 1;
     memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
     memset(ctx->flight, 0, sizeof(ctx->flight));
-    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true; ctx->chroma_cap = 60;
+    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true; ctx->i_stream_b = false; ctx->chroma_cap = 60;
     ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;

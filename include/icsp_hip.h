@@ -29,7 +29,7 @@
  *   ICSP_I_GROUPS  1..2  parts (launches on separate streams) an all-intra batch of more frames than CUs is encoded in (default 2)
  *   ICSP_INTRA_FORM 8|32 lanes per 8x8 block in the intra luma kernel: 32 = latency form (two blocks per wave), 8 = throughput
  *                        form (eight blocks per wave); default: by frames in flight per CU and geometry class -- 32 while every
- *                        frame has a CU of its own, 8 above (the rule table kFormRules in icsp_device.hip, profiles/r04_sweep.json)
+ *                        frame has a CU of its own, 8 above (the rule table kFormRules in icsp_device.hip, profiles/r05_sweep.json)
  *   ICSP_INTRA_GROUP 0|1|2  8-lane intra kernel: 2 = block rows run one wavefront step apart in pairs (96 steps per CIF frame instead
  *                        of 114, four waves; frames whose widest step fits eight waves), 1 = two steps apart throughout (the plain
  *                        wavefront: what 720p / 1088p frames take anyway), 0 (default) = pairs wherever they can be built
@@ -42,7 +42,11 @@
  *                        launch (default 60; 0: always the plain chroma launch)
  *   ICSP_I_CHROMA_ON_CHAIN 0|1  1 (default): a range placed whole takes its I frames' chroma kernels to the front of its own chain
  *                        stream; 0: they stay on the second stream with the luma kernel
- *                        (icsp_encode_resident); default 1
+ *   ICSP_I_STREAM_B 0|1  1 (default): when the caller alternates between independent IPPP ranges, the I-frame launches of every other
+ *                        range run on a stream of their own instead of following the first range's on the second stream; 0: one I stream
+ *   ICSP_TIMELINE_DUMP <file>  (diagnostics) every kernel launch of the context between HIP events; "kernel stream start_us end_us"
+ *                        lines, against one base event, appended to <file> whenever results are collected (tools/timeline_events.py).
+ *                        Costs the host two event records per launch
  *   ICSP_FAKE_DEVICES 2..64 (test hook, read once per process) the library presents that many devices, device d being physical device
  *                        d mod (real devices) with per-device records of its own (search tables, shared transfer streams, turns):
  *                        the multi-device paths of a host run on a one-GPU box

@@ -38,13 +38,18 @@ for k in range(100 // (MANY if MANY else 1) + 2):
     one(k)
 enc.sync()
 best = 0
+host = 1.0
 for rep in range(3):
     t0 = time.perf_counter()
     calls = max(1, passes // MANY) if MANY else passes
     for k in range(calls):
         one(k)
+    t1 = time.perf_counter()
     enc.sync()
     dt = (time.perf_counter() - t0) / calls
-    best = max(best, (n * MANY if MANY else n) / dt)
+    if (n * MANY if MANY else n) / dt > best:
+        best = (n * MANY if MANY else n) / dt
+        host = (t1 - t0) / (dt * calls)            # share of the region the host spent issuing the calls (near 1: the host is what paces it)
+print(f"host {host:.2f} ", end="")
 print(f"{W}x{H} " * ((W, H) != (352, 288)) + f"period={period} qp={qp} n={n} ranges={R}: {best:10.0f} fps  ({n / best * 1e3:.4f} ms/step) env={ {k: v for k, v in os.environ.items() if k.startswith(('HIP_', 'ICSP_', 'GPU_'))} }")
 enc.close()
