@@ -384,7 +384,6 @@ struct icsp_ctx {
     Flight flight[kMaxFlights];
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
     int last_form, last_nw, last_ring, last_whole, last_groups, last_rowgroup;     // what the last encode chose (icsp_debug_last_choice)
-    bool chroma_on_chain;             // ICSP_I_CHROMA_ON_CHAIN
     bool i_stream_b;                  // ICSP_I_STREAM_B=0: the I frames of every range on stream2 (as before round 5); default: those of a range
                                       // placed whole on chain stream 1 on a stream of their own (pstream[2])
     int chroma_cap;                   // ICSP_CHROMA_CAP: KB of LDS reserved (not used) by the all-intra chroma launch of a small range placed whole
@@ -826,16 +825,13 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     else if (joined || !lazy || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }   // after what was queued on `stream` (uploads ...)
     {
         FrameSel fs{ first, L, G, nullptr };
-        // A range placed whole on one chain stream: its I frames' chroma kernels go in front of the chain instead of in front
-        // of the luma kernel -- stream2 sets the pace of the alternating regime (the ranges' luma wavefront kernels, 0.22 ms of
-        // latency each, follow each other there), and the chain stream has slack (ICSP_I_CHROMA_ON_CHAIN=0: as before).
-        // (Up to about 32 GOPs per range: two ranges of 30 GOPs alternating 1.246 M frames/s against 1.135 M; with 35 and 40 GOPs the
-        //  chain is the longer path and the chroma kernels are better off beside the luma kernel again: 1.209 / 1.243 M, 1.303 / 1.337 M,
-        //  three ranges in rotation 1.266 / 1.330 M; from 60 GOPs on it makes no difference -- tools/sweep_regimes.py.)
-        hipStream_t scs = (whole && ctx->chroma_on_chain && G <= 32) ? chain_stream(0) : s2;
-        LT(ctx, ICSP_K_CHROMA_DC, scs, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, scs, g, fs, b); });
+        // (Rounds 3-4 took the chroma kernels of a range placed whole to the front of its chain stream, when the I frames of both
+        //  alternating ranges shared stream2 and set the pace.  With an I stream per chain it is the chains that set it, and the
+        //  chroma kernels are better off in front of the luma kernel again: two ranges of 30 GOPs 1.38 -> 1.43 M frames/s, three in
+        //  rotation 1.33 -> 1.37 M, two of 15 GOPs 0.96 -> 0.99 M, of 60 GOPs level -- profiles/r05_exp_istream.txt.)
+        LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
-        LT(ctx, ICSP_K_RESIDUAL, scs, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, scs, g, fs, b, 0, cwgs, sc_); });
+        LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2, true); });
         if (!single) {
             HIPQ(hipEventRecord(ctx->ev_join, s2));
@@ -969,10 +965,9 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
     else if (joined || ctx->st_ahead) { if (int rc = fork_all(ctx)) return rc; }
     {
         FrameSel fs{ 0, 0, G, F->d_tab };
-        hipStream_t scs = (ctx->chroma_on_chain && G <= 32) ? cs : s2;
-        LT(ctx, ICSP_K_CHROMA_DC, scs, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, scs, g, fs, b); });
+        LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
-        LT(ctx, ICSP_K_RESIDUAL, scs, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, scs, g, fs, b, 0, cwgs, sc_); });
+        LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
         LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2, true); });
         HIPQ(hipEventRecord(ctx->ev_join, s2));
         HIPQ(hipStreamWaitEvent(cs, ctx->ev_join, 0));
@@ -1571,7 +1566,6 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     ctx->p_dirty = false; ctx->sticky = 0;
     memset(ctx->flight, 0, sizeof(ctx->flight));
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
-    { int v_ = 1; if (!env_int("ICSP_I_CHROMA_ON_CHAIN", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_on_chain = v_ != 0; }
     { int v_ = 1; if (!env_int("ICSP_I_STREAM_B", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->i_stream_b = v_ != 0; }
     { int v_ = 60; if (!env_int("ICSP_CHROMA_CAP", 0, 120, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_cap = v_; }
     ctx->last_form = ctx->last_nw = ctx->last_ring = ctx->last_whole = ctx->last_groups = 0;
@@ -2436,7 +2430,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->device = 0; ctx->slot = 0; ctx->max_frames = 1;
     memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
     memset(ctx->flight, 0, sizeof(ctx->flight));
-    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->chroma_on_chain = true; ctx->i_stream_b = false; ctx->chroma_cap = 60;
+    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->i_stream_b = false; ctx->chroma_cap = 60;
     ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;

@@ -8,7 +8,7 @@ Regimes: geometry {CIF, 352x576, 4CIF, 720p, 1088p} x batch {100 ... 3390 CIF fr
 with everything left to the library (default) and with one knob forced at a time:
 
     all-intra: ICSP_INTRA_FORM 8 (plain wavefront) / 32, ICSP_INTRA_GROUP 2 / 1 (rows chained in pairs / the plain wavefront), ICSP_CHROMA_CAP 0, ICSP_WHOLE 0 (two ranges or more), ICSP_I_GROUPS 1 (one range)
-    period 10: ICSP_P_GROUPS 1 / 2, ICSP_WHOLE 0 and ICSP_I_STREAM_B 0 (two ranges or more), ICSP_INTRA_FORM 8 / 32, ICSP_INTRA_GROUP 2 (the I step), ICSP_I_CHROMA_ON_CHAIN 0
+    period 10: ICSP_P_GROUPS 1 / 2, ICSP_WHOLE 0 and ICSP_I_STREAM_B 0 (two ranges or more), ICSP_INTRA_FORM 8 / 32, ICSP_INTRA_GROUP 2 (the I step)
 
 Every setting produces the same bytes (tests/); this is about speed only.  Writes the table and a summary (worst default / best
 ratio, the regimes below 0.97) as JSON.  --quick: ten regimes -- the headline three and the closest calls of profiles/r04_sweep.json --
@@ -27,7 +27,7 @@ from icspcodec_amd import capi, clipgen  # noqa: E402
 GEOMS = {"CIF": (352, 288), "352x576": (352, 576), "4CIF": (704, 576), "720p": (1280, 720), "1088p": (1920, 1088)}
 BATCHES = [100, 200, 250, 270, 300, 350, 400, 600, 1000, 3390]          # CIF frames' worth of macroblocks
 KNOBS_AI = [("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_INTRA_GROUP", "1"), ("ICSP_CHROMA_CAP", "0"), ("ICSP_WHOLE", "0"), ("ICSP_I_GROUPS", "1")]
-KNOBS_IP = [("ICSP_P_GROUPS", "1"), ("ICSP_P_GROUPS", "2"), ("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_I_CHROMA_ON_CHAIN", "0"), ("ICSP_I_STREAM_B", "0")]
+KNOBS_IP = [("ICSP_P_GROUPS", "1"), ("ICSP_P_GROUPS", "2"), ("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_I_STREAM_B", "0")]
 # --quick: (geometry, batch, period, ranges, knobs to force); from profiles/r04_sweep.json's lowest default / best ratios
 QUICK = [("CIF", 300, 0, 2, [("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "1"), ("ICSP_CHROMA_CAP", "0")]),
          ("CIF", 300, 10, 2, [("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "32")]),
@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--budget-s", type=float, default=0.12)
     ap.add_argument("--geoms", default=",".join(GEOMS))
     ap.add_argument("--regimes", default="", help="only these: geometry:batch:period:ranges,...")
+    ap.add_argument("--periods", default="0,10", help="of the full sweep: only these intra periods")
+    ap.add_argument("--ranges", default="1,2,3", help="of the full sweep: only these numbers of ranges in rotation")
+    ap.add_argument("--batches", default=",".join(str(b) for b in BATCHES), help="of the full sweep: only these batch sizes")
     a = ap.parse_args()
     regimes = []
     quick_knobs = {}
@@ -106,9 +109,9 @@ def main():
         quick_knobs = {q[:4]: q[4] for q in QUICK}
     else:
         for g in a.geoms.split(","):
-            for b in BATCHES:
-                for period in (0, 10):
-                    for r in (1, 2, 3):
+            for b in [int(x) for x in a.batches.split(",")]:
+                for period in [int(x) for x in a.periods.split(",")]:
+                    for r in [int(x) for x in a.ranges.split(",")]:
                         regimes.append((g, b, period, r))
     rows = []
     t_all = time.time()
