@@ -832,7 +832,8 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
         LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
-        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2, true); });
+        // (frames in flight: a range placed whole has another one's I frames, on their own stream, beside its own)
+        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, whole ? 2 * G : G, s2, true); });
         if (!single) {
             HIPQ(hipEventRecord(ctx->ev_join, s2));
             for (int k = 0; k < NG; k++) HIPQ(hipStreamWaitEvent(chain_stream(k), ctx->ev_join, 0));
@@ -968,7 +969,7 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
         LT(ctx, ICSP_K_CHROMA_DC, s2, [&] { hipLaunchKernelGGL(k_chroma_dc, dim3(G, 2), dim3(256), (size_t)g.nmb * 2, s2, g, fs, b); });
         const int sc_ = xcd_slices(G, cwgs);
         LT(ctx, ICSP_K_RESIDUAL, s2, [&] { hipLaunchKernelGGL(k_residual8, xcd_grid2(G, cwgs, sc_), dim3(256), 0, s2, g, fs, b, 0, cwgs, sc_); });
-        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, G, s2, true); });
+        LT(ctx, ICSP_K_INTRA_LUMA, s2, [&] { launch_intra_luma(ctx, g, fs, b, G, 2 * G, s2, true); });
         HIPQ(hipEventRecord(ctx->ev_join, s2));
         HIPQ(hipStreamWaitEvent(cs, ctx->ev_join, 0));
     }
@@ -1072,15 +1073,15 @@ template <int NW> void launch_intra8_pairs(const Geo& g, const FrameSel& fs, con
 //     26 KB of LDS; from where frames share CUs, at every load;
 //   8-lane plain (k_intra_luma8<.., 0>): frames whose widest pairs step does not fit eight waves (720p, 1088p).
 // The only decision with thresholds is where the latency form ends, in frames in flight per CU (G_all / CUs) by geometry class and by
-// what runs beside the launch.  The thresholds are data: each a crossover measured by tools/sweep_regimes.py (profiles/r04_sweep.json:
-// 300 regimes x forced knobs; the default within 3 % of the best forced setting everywhere), named beside its entry.
+// what runs beside the launch.  The thresholds are data: each a crossover measured by tools/sweep_regimes.py (profiles/r05_sweep.json:
+// 300 regimes x forced knobs, this round's kernels and stream layout), named beside its entry.
 enum GeoClass { GEO_CIF, GEO_TALL, GEO_4CIF, GEO_WIDE };            // by the waves of two blocks the widest plain step needs (<= 16 / 17-24 / more) and the aspect
 enum Beside { BESIDE_ALONE, BESIDE_RANGE, BESIDE_P_STEPS, BESIDE_P_STEPS_MANY };   // nothing / another range's launches / P-step kernels (up to, more than 12 I frames)
 struct FormRule { int geo, pairs, beside, lat_end20; const char* measured; };     // pairs, beside: -1 = any; lat_end20: the 32-lane form up to lat_end20 / 20 frames per CU
 const FormRule kFormRules[] = {
     { GEO_WIDE, -1, -1,                  0,  "1280x720, 1920x1088: the 32-lane form 15-28 % behind at any load (two rounds and more per step)" },
     { GEO_4CIF,  1, BESIDE_P_STEPS,      0,  "704x576, up to 12 I frames beside P steps: pairs +3 %" },
-    { GEO_4CIF,  1, BESIDE_P_STEPS_MANY, 4,  "704x576, 13-51 I frames beside P steps: 32-lane +3 %; more: pairs +3 % (20 I frames 27.9 / 29.1 k frames/s)" },
+    { GEO_4CIF,  1, BESIDE_P_STEPS_MANY, 0,  "704x576, more I frames beside P steps: pairs +2-5 % (15 I frames, one range or several; 25 with two ranges or three) except 25 I frames of ONE range (-3 %)" },
     { GEO_4CIF,  1, BESIDE_ALONE,        0,  "704x576, a launch on its own: pairs at any load (100 frames 0.167 / 0.173 M frames/s)" },
     { GEO_4CIF,  1, BESIDE_RANGE,        16, "704x576, two ranges of 100 frames alternating: 0.313 M 32-lane / 0.291 M pairs; of 250: 0.48 / 0.53 M" },
     { GEO_4CIF,  0, BESIDE_P_STEPS,      4,  "4CIF-class frames too wide for pairs, beside P steps (round 3's rule for the plain form)" },
@@ -1090,8 +1091,8 @@ const FormRule kFormRules[] = {
     { GEO_TALL, -1, BESIDE_P_STEPS_MANY, 2,  "352x576, 13-25 I frames beside P steps: 32-lane +1-5 % (17 / 20 I frames); 30 / 50 I frames: pairs +2-5 %" },
     { GEO_TALL, -1, BESIDE_ALONE,        0,  "352x576, a launch on its own: pairs (50 frames +5.6 %, 100-150 +1 %, 175-200 -1.3 %, 300 and more +20 %)" },
     { GEO_TALL, -1, BESIDE_RANGE,        20, "352x576: two ranges of 125 frames 0.66 M 32-lane / 0.59 M pairs, of 175 frames 0.62 / 0.79 M; one frame per CU level" },
-    { GEO_CIF,  -1, BESIDE_P_STEPS,      4,  "CIF I step beside P steps: 30 GOPs 1.25 M 32-lane / 1.13 M pairs, 60 GOPs 1.42 / 1.48 M (since the slots rotate)" },
-    { GEO_CIF,  -1, BESIDE_P_STEPS_MANY, 4,  "as above (100 GOPs 1.51 / 1.54 M, 339 GOPs 1.62 / 1.66 M)" },
+    { GEO_CIF,  -1, BESIDE_P_STEPS,      4,  "CIF I step beside P steps, up to 12 I frames in flight: 32-lane (10 GOPs of one range +5 %)" },
+    { GEO_CIF,  -1, BESIDE_P_STEPS_MANY, 4,  "CIF, more: pairs from 52 I frames in flight -- one range of 40 GOPs 32-lane +17 %, of 60 GOPs pairs +1 %; two ranges (both count) of 20 GOPs 32-lane +5 %, of 27 / 30 / 40 GOPs pairs +0-4 / +3 / +5 %" },
     { GEO_CIF,  -1, -1,                  20, "CIF: pairs from one frame per CU on (two ranges of 150 / 300 / 3390 frames: 1.00 / 1.41 / 1.47 M 32-lane, 1.05 / 1.84 / 2.36 M pairs)" },
 };
 
