@@ -597,12 +597,41 @@ int fork_all(icsp_ctx* ctx)
     return 0;
 }
 
+// The streams of a device's contexts are kept when a context goes and handed to the next one that asks (by priority).  Not to save
+// their set-up time alone: WHICH hardware queue a stream gets depends on how many streams the process made before it, and the
+// regime that keeps four streams busy (two IPPP ranges alternating: two chains, two I streams) runs 17 % slower when two other
+// streams -- never used -- were made first, 35 % slower behind three, whatever GPU_MAX_HW_QUEUES says; streams made AFTER the four
+// cost nothing (tools/exp_prelude.py, profiles/r05_stream_order.txt).  So a process's first context makes its streams early (the
+// transfer streams come behind them, icsp_copy_streams) and later contexts inherit them instead of making new ones behind
+// whatever else the process has created since.  A poisoned context's streams are destroyed, not kept.
+struct StreamPool { std::mutex m; std::vector<std::pair<int, hipStream_t>> idle[64]; };
+StreamPool& stream_pool() { static StreamPool* p = new StreamPool; return *p; }      // (never destroyed: contexts may go during static destruction)
+hipError_t stream_get(int slot, int prio, hipStream_t* out)
+{
+    {
+        StreamPool& sp = stream_pool();
+        std::lock_guard<std::mutex> l(sp.m);
+        auto& v = sp.idle[slot & 63];
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i].first == prio) { *out = v[i].second; v.erase(v.begin() + (long)i); return hipSuccess; }
+    }
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+}
+void stream_put(int slot, int prio, hipStream_t s, bool healthy)
+{
+    if (!s) return;
+    if (!healthy || hipStreamQuery(s) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(s); return; }
+    StreamPool& sp = stream_pool();
+    std::lock_guard<std::mutex> l(sp.m);
+    sp.idle[slot & 63].emplace_back(prio, s);
+}
+
 // stream2 (I-frame chroma / all I-frame kernels) is created by the first encode or decode of a context that is not in
 // single-stream mode: a stream costs 10-25 ms of set-up on this runtime (a hardware queue + its 4 MB and 16 MB buffers)
 int second_stream(icsp_ctx* ctx)
 {
     if (ctx->stream2 || ctx->single) return 0;
-    HIPCHK(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, ctx->prio_lo));
+    HIPCHK(stream_get(ctx->slot, ctx->prio_lo, &ctx->stream2));
     ctx->st_ahead = true;                               // ordered after nothing yet: the next encode forks
     return 0;
 }
@@ -612,7 +641,7 @@ int group_streams(icsp_ctx* ctx, int ng)
 {
     for (int k = 1; k < ng && k < kMaxPGroups; k++)
         if (!ctx->pstream[k]) {
-            HIPCHK(hipStreamCreateWithPriority(&ctx->pstream[k], hipStreamNonBlocking, ctx->prio_hi));
+            HIPCHK(stream_get(ctx->slot, ctx->prio_hi, &ctx->pstream[k]));
             HIPCHK(hipEventCreateWithFlags(&ctx->ev_pjoin[k], hipEventDisableTiming));
             ctx->st_ahead = true;                       // a new stream is ordered after nothing: the next encode forks
         }
@@ -1416,6 +1445,12 @@ int icsp_copy_streams(icsp_ctx_t* ctx, int shared)
     static hipStream_t up[64], down[64];
     std::lock_guard<std::mutex> l(m);
     const int d = ctx->slot & 63;
+    if (!up[d] && !ctx->single) {
+        // the device's compute streams before its transfer streams (StreamPool: the order the process makes its streams in decides
+        // which hardware queues the busy ones get)
+        if (int rc = second_stream(ctx)) return rc;
+        if (int rc = group_streams(ctx, kMaxPGroups)) return rc;
+    }
     if (!up[d]) {
         // The two streams must sit on two DMA engines.  A stream keeps the engine its first copy was given, the lowest idle one
         // at that moment.  So the download stream's first copy is made while the upload stream is kept busy, and the pair is
@@ -1590,7 +1625,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     // the main stream carries the latency-bound kernels and gets the higher priority; stream2 (I-frame chroma) fills in
     int prio_lo = 0, prio_hi = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi) != hipSuccess) { (void)hipGetLastError(); prio_lo = prio_hi = 0; }
-    if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
+    ctx->prio_lo = prio_lo; ctx->prio_hi = prio_hi;        // (before the first stream: icsp_destroy hands streams back by priority)
+    if ((e = stream_get(ctx->slot, prio_hi, &ctx->stream)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipStreamCreate", e);
     phase("priority range + stream");
     ctx->prio_lo = prio_lo;            // stream2 is created by the first encode / decode that uses it (second_stream)
     if ((e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess) return fail(ICSP_ERR_HIP, "hipEventCreate", e);
@@ -1694,9 +1730,11 @@ int icsp_destroy(icsp_ctx_t* ctx)
         if (f.h_tab) (void)hipHostFree(f.h_tab);
         free(f.many_list);
     }
-    if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
-    for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) (void)hipEventDestroy(ctx->ev_pjoin[k]); if (ctx->pstream[k]) (void)hipStreamDestroy(ctx->pstream[k]); }
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    // the streams stay with the device for its next context (stream_get); they were waited for above
+    const bool healthy = ctx->sticky == 0;
+    stream_put(ctx->slot, ctx->prio_hi, ctx->stream, healthy);
+    stream_put(ctx->slot, ctx->prio_lo, ctx->stream2, healthy);
+    for (int k = 1; k < kMaxPGroups; k++) { if (ctx->ev_pjoin[k]) (void)hipEventDestroy(ctx->ev_pjoin[k]); stream_put(ctx->slot, ctx->prio_hi, ctx->pstream[k], healthy); }
     (void)hipGetLastError();
     delete ctx;
     return ICSP_OK;

@@ -78,10 +78,12 @@ def test_alternating_disjoint_ranges_without_a_sync(period, q, name_a, groups, m
     enc.close()
 
 
-@pytest.mark.parametrize("period,q", [(0, 16), (5, 8)])
-def test_three_ranges_in_rotation_change_streams(period, q):
+@pytest.mark.parametrize("period,q,istream_b", [(0, 16, "1"), (5, 8, "1"), (5, 8, "0")])
+def test_three_ranges_in_rotation_change_streams(period, q, istream_b, monkeypatch):
     """Three ranges over two chain streams: every range comes back on the other stream than its previous pass and has to wait
-    for that pass (ev_done).  Unequal sizes, so that the passes really are in flight together."""
+    for that pass (ev_done) -- and, IPPP, its I frames on the other I stream (ICSP_I_STREAM_B=0: all of them on one).  Unequal
+    sizes, so that the passes really are in flight together."""
+    monkeypatch.setenv("ICSP_I_STREAM_B", istream_b)
     sizes = [120, 35, 80]
     firsts = [0, 120, 155]
     clip = clipgen.synth_clip("hallmonitorlike", sum(sizes))
