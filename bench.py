@@ -173,6 +173,15 @@ def main():
                 os.sched_setaffinity(0, _aff_bound)
             except OSError:
                 pass
+    # The device's four compute streams before anything else of this process creates streams (RCCL does, below): which hardware
+    # queues they get depends on the order of creation (profiles/r05_stream_order.txt).  A throw-away context
+    # encodes two tiny IPPP ranges in turn -- that makes all four -- and is closed; the legs' contexts inherit its streams.
+    _rs = capi.Encoder(W, H, 8, 8, 2, device=local, max_frames=8)
+    _rs.upload(np.zeros((8, W * H * 3 // 2), np.uint8))
+    for _k in range(4):
+        _rs.encode_resident((_k & 1) * 4, 4)
+    _rs.sync()
+    _rs.close()
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))      # nccl == RCCL on ROCm
