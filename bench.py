@@ -721,7 +721,7 @@ def main():
                        "this key: that one is chip_level.frac, kept beside it every round",
             "achieved_is": "the contract's per-launch figure: algorithmic_bytes_per_launch / avg_launch_ms, the launch's own duration "
                            "under HIP events on the stream it runs on (every 4th step of the timed region).  Two such launches are in "
-                           "flight at any time (two batches on two streams, profiles/r04_overlap.json), each on about half the "
+                           "flight at any time (two batches on two streams, profiles/r*_overlap.json), each on about half the "
                            "chip's issue slots: see chip_level",
             "traffic_is": "HBM-side bytes of one launch of the kernel (rocprofv3 TCC counters of a 300-frame launch of the same kernel variant, "
                           "tools/pmc_workload.py -> profiles/traffic.json)",
