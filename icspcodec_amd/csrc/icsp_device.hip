@@ -1609,8 +1609,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     int no_fuse = 0;
     ctx->force_intra_form = 0; ctx->force_intra_group = 0; ctx->last_rowgroup = 0;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
-    ctx->p_groups = 2;                 // measured (300 CIF frames, period 10): 1 group 0.75 M frames/s, 2 groups 0.89 M, 3 groups -- a fourth
-                                       // busy stream of the context -- 0.27 M, whatever the stream priorities and GPU_MAX_HW_QUEUES
+    ctx->p_groups = 2;                 // measured, one range of 30 / 60 / 339 CIF GOPs again and again: 1 group 0.91 / 1.27 / 1.90 M frames/s,
+                                       // 2 groups 0.97 / 1.48 / 1.94 M, 3 groups 0.97 / 1.44 / 1.91 M (round 3 saw 0.27 M with three: see StreamPool)
     ctx->i_groups = 2;
     if (!env_int("ICSP_NO_FUSE", 0, 1, &no_fuse) || !env_int("ICSP_P_GROUPS", 1, kMaxPGroups, &ctx->p_groups) || !env_int("ICSP_I_GROUPS", 1, 2, &ctx->i_groups) ||
         !env_int("ICSP_INTRA_FORM", 8, 32, &ctx->force_intra_form) ||
