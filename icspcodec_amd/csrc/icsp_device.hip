@@ -2337,6 +2337,14 @@ int icsp_single_stream(icsp_ctx_t* ctx, int on)
 // What the last icsp_encode_resident chose (bench.py puts it beside its figures, so that a line explains its own regime):
 // form of the intra luma kernel (8 / 32 lanes per block), its waves per workgroup, reconstruction through the LDS ring or not, whether the range went
 // whole onto one chain stream, GOP groups.  Any pointer may be null.
+int icsp_debug_stream_pool(int device_id)
+{
+    if (device_id < 0) return 0;
+    StreamPool& sp = stream_pool();
+    std::lock_guard<std::mutex> l(sp.m);
+    return (int)sp.idle[device_id & 63].size();
+}
+
 int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups, int* intra_row_group)
 {
     ENTER(ctx);

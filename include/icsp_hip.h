@@ -85,7 +85,10 @@ typedef struct {
 typedef struct icsp_ctx icsp_ctx_t; /* opaque: device buffers, stream and scratch for ONE device */
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
-/* max_frames = capacity of the resident frame store (inputs + all outputs stay in HBM). */
+/* max_frames = capacity of the resident frame store (inputs + all outputs stay in HBM).
+ * A context's HIP streams (up to four) are taken from, and on icsp_destroy given back to, a per-device pool that lives as long as
+ * the process: which hardware queue a stream gets depends on the order the process created its streams in, so later contexts
+ * inherit the early ones.  Create the first context before other HIP streams of the process where possible. */
 int icsp_create(icsp_ctx_t** out, const icsp_params_t* params, int device_id, int max_frames);
 int icsp_destroy(icsp_ctx_t* ctx);
 const char* icsp_strerror(int status);
@@ -161,6 +164,8 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
  * 8-lane form wrote the reconstruction through its LDS ring (0/1), range placed whole on one chain stream (0/1), GOP groups, block
  * rows of the 8-lane form's wavefront chained in groups of (4) or not (0).  Any pointer may be NULL.  For reports. */
 int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups, int* intra_row_group);
+/* Streams idle in the pool of device `device_id` (of this process): what destroyed contexts left for the next one.  For tests. */
+int icsp_debug_stream_pool(int device_id);
 /* Test hook, needs no device: a context shell in the state a failed launch-path call leaves behind (poisoned).  Every entry
  * point answers ICSP_ERR_HIP on it without touching the runtime; release it with icsp_destroy. */
 int icsp_debug_poisoned_context(icsp_ctx_t** out);

@@ -325,3 +325,29 @@ def test_two_coalesced_lists_alternating_without_a_sync():
         enc.encode_resident_many(lb)
     _cmp(enc.download(0, 600), want, "two lists alternating: ")
     enc.close()
+
+
+def test_streams_stay_with_the_device_for_the_next_context():
+    """A destroyed context leaves its streams in the device's pool and the next context takes them from there instead of making new
+    ones (which hardware queues the busy streams get depends on the order the process made its streams in: DESIGN.md section 4).
+    Two IPPP ranges alternating keep four streams busy; a second context doing the same must not grow the pool."""
+    lib = capi.load()
+    clip = clipgen.synth_clip("stefanlike", 40)
+
+    def one_context():
+        enc = capi.Encoder(W, H, 8, 8, 5, max_frames=40)
+        enc.upload(clip)
+        for k in range(6):
+            enc.encode_resident((k & 1) * 20, 20)
+        got = enc.download(0, 40)
+        enc.close()
+        return got
+    a = one_context()
+    idle = lib.icsp_debug_stream_pool(0)
+    assert idle >= 4, idle
+    b = one_context()
+    assert lib.icsp_debug_stream_pool(0) == idle
+    for k in KEYS:
+        assert np.array_equal(a[k], b[k]), k
+    for f in (0, 20):
+        _cmp({k: a[k][f: f + 20] for k in KEYS}, po.encode_sequence(clip[f: f + 20], W, H, 8, 8, 5, nthreads=NT), f"range at {f}: ")
