@@ -235,15 +235,15 @@ def main():
                      "the chip's vector issue slots the leg fills -- the ceiling that binds these kernels (DESIGN.md section 5)"}
         return out
 
-    def timed(enc, n, steps, warmup, dominant, alternate=True):
+    def timed(enc, n, steps, warmup, dominant, alternate=True, ranges=2):
         """The K-step timed region, `a.repeats` times over (each bracketed by barrier + synchronize; the list of their
         durations comes back, max over ranks each): steps alternating between the resident batches at slots [0, n) and
-        [n, 2n) -- or, alternate=False, the batch at [0, n) again and again -- with HIP events only around the dominant kernel
+        [n, 2n) (`ranges` batches in rotation) -- or, alternate=False, the batch at [0, n) again and again -- with HIP events only around the dominant kernel
         (none if it is None); then four untimed passes with events on every kernel."""
         step_no = [0]
 
         def one_step():
-            enc.encode_resident((step_no[0] & 1) * n if alternate else 0, n)
+            enc.encode_resident((step_no[0] % ranges) * n if alternate else 0, n)
             step_no[0] += 1
         for _ in range(SETTLE_PASSES):              # fixed settle (clock ramp, instruction and TLB warm-up): independent of W
             one_step()
@@ -325,12 +325,18 @@ def main():
     ncore = min(os.cpu_count() or 1, 64)
     clip = clipgen.synth_clip("foremanlike", NFRAMES, first_frame=rank * 2 * NFRAMES)
     clip_b = clipgen.synth_clip("foremanlike", NFRAMES, first_frame=rank * 2 * NFRAMES + NFRAMES)
-    enc = capi.Encoder(W, H, 16, 16, 0, device=local, max_frames=2 * NFRAMES)
+    enc = capi.Encoder(W, H, 16, 16, 0, device=local, max_frames=3 * NFRAMES)
     enc.upload(clip, first=0)
     enc.upload(clip_b, first=NFRAMES)
     dts_ai, prof, (ms_ai, n_ai) = timed(enc, NFRAMES, a.steps, a.warmup, "k_intra_luma")
     dt = med(dts_ai)
     choice_ai = enc.last_choice()
+    # beside `value`, never instead of it (its regime stays two batches, like for like since round 3): THREE resident batches in
+    # rotation -- a host with a ring of three chunk slots.  The library then keeps three batches in flight on three chain streams
+    # (round 5), where a batch that alternates with one other must follow its own previous pass.
+    enc.upload(clipgen.synth_clip("foremanlike", NFRAMES, first_frame=rank * 2 * NFRAMES + 2 * NFRAMES), first=2 * NFRAMES)
+    dts_r3, _, _ = timed(enc, NFRAMES, a.steps, a.warmup, None, ranges=3)
+    choice_r3 = enc.last_choice()
     # the regime of rounds 1 and 2, kept beside `value` so that round-over-round figures stay like for like: ONE
     # resident 300-frame batch encoded again and again (the library then runs it in two parts on two streams)
     dts_same, _, (ms_same, n_same) = timed(enc, NFRAMES, a.steps, a.warmup, "k_intra_luma", alternate=False)
@@ -795,6 +801,11 @@ def main():
         "ms_per_step": round(dt / a.steps * 1e3, 4),
         "value_is": "median of the repeats of the K-step timed region (each bracketed by barrier + synchronize)",
         "repeats": spread(dts_ai, world * NFRAMES * a.steps),
+        "value_three_batches": round(world * NFRAMES * a.steps / med(dts_r3), 1),
+        "three_batches": {"is": "the same K-step regions with THREE resident 300-frame batches in rotation instead of two (a ring of three "
+                                "chunk slots): three batches in flight on three chain streams; secondary, `value` keeps its two-batch regime",
+                          "ms_per_step": round(med(dts_r3) / a.steps * 1e3, 4), "repeats": spread(dts_r3, world * NFRAMES * a.steps),
+                          "regime": choice_r3},
         "value_same_range": round(world * NFRAMES * a.steps / med(dts_same), 1),
         "same_range": {"is": "the regime of rounds 1-2, for like-for-like comparison across rounds: ONE resident 300-frame batch "
                              "encoded again and again (two parts on two streams), K steps, same repeats",

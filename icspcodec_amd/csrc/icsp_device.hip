@@ -383,6 +383,8 @@ struct icsp_ctx {
     bool p_dirty;
     Flight flight[kMaxFlights];
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
+    int prev2_first, prev2_n;         // ... and of the call before it (three ranges in rotation -> three chain streams, all-intra)
+    bool chains3;                     // ICSP_CHAINS3=0: two chain streams whatever the rotation (comparison)
     int last_form, last_nw, last_ring, last_whole, last_groups, last_rowgroup;     // what the last encode chose (icsp_debug_last_choice)
     bool i_stream_b;                  // ICSP_I_STREAM_B=0: the I frames of every range on stream2 (as before round 5); default: those of a range
                                       // placed whole on chain stream 1 on a stream of their own (pstream[2])
@@ -751,6 +753,17 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // it) gets every range WHOLE on one of the two chain streams, taking turns: two whole batches side by side keep twice the
     // frames in flight that the two halves of one batch do.
     const bool whole = !single && lazy && ctx->whole_ok && ctx->last_n > 0 && (first >= ctx->last_first + ctx->last_n || ctx->last_first >= first + n);
+    auto apart = [](int a, int an, int b_, int bn) { return a >= b_ + bn || b_ >= a + an; };
+    // Three all-intra ranges in rotation (this one, the one before and the one before that pairwise disjoint): THREE chain streams in
+    // turn, so that three whole batches are in flight instead of two -- with the chroma stream that makes the four streams the runtime
+    // has hardware queues for.  CIF, frames/s with two chain streams -> three: three ranges of 100 / 150 / 200 / 220 frames 0.91 -> 1.03,
+    // 1.10 -> 1.48, 1.43 -> 1.89, 1.58 -> 2.03 M; of 250 / 300 / 350 / 400 frames 1.76 -> 2.16, 1.72 -> 2.16, 1.92 -> 2.34, 1.98 -> 2.34 M; four
+    // of 75 / 150 / 300: 0.70 -> 0.95, 1.12 -> 1.46, 1.70 -> 2.10 M; 352x576 3 x 100: 0.53 -> 0.64 M, 704x576 3 x 50 / 100: 0.17 -> 0.25, 0.31 ->
+    // 0.39 M, 720p 3 x 30: 58 -> 86 k, 1088p 3 x 15: 16 -> 24 k (profiles/r05_exp_chains3.txt).  Two ranges alternating stay as they were
+    // (a range follows its own previous pass: two in flight is all there can be).
+    const bool three = ctx->chains3 && whole && L == 1 && ctx->prev2_n > 0 && apart(first, n, ctx->prev2_first, ctx->prev2_n) &&
+                       apart(ctx->last_first, ctx->last_n, ctx->prev2_first, ctx->prev2_n);
+    ctx->prev2_first = ctx->last_first; ctx->prev2_n = ctx->last_n;
     ctx->last_first = first; ctx->last_n = n;
     int NG = ctx->p_groups;
     // keep every group's launches wide enough to be worth splitting: a dozen GOPs per group (tools/sweep_regimes.py, one CIF range
@@ -769,12 +782,13 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     if (int rc = flight_events(ctx, F, NG)) return rc;
     bool moved = false;                                // a whole range on the other stream than its previous pass
     if (whole) {
-        if (int rc = group_streams(ctx, 2)) return rc;
+        if (int rc = group_streams(ctx, three ? 3 : 2)) return rc;
+        if (!three) ctx->rr &= 1;
         moved = same && F->sidx != ctx->rr;
-        F->sidx = ctx->rr; ctx->rr ^= 1;               // calls take the two chain streams in turn
+        F->sidx = ctx->rr; ctx->rr = three ? (ctx->rr + 1) % 3 : (ctx->rr ^ 1);               // calls take the chain streams in turn
     }
     // stream of chain / part k of this range
-    auto chain_stream = [&](int k) { return whole ? (F->sidx ? ctx->pstream[1] : st) : (k == 0 ? st : ctx->pstream[k]); };
+    auto chain_stream = [&](int k) { return whole ? (F->sidx ? ctx->pstream[F->sidx] : st) : (k == 0 ? st : ctx->pstream[k]); };
     if (moved && F->done_valid) HIPQ(hipStreamWaitEvent(chain_stream(0), F->ev_done, 0));
     if (L == 1) {
         // ---- all-intra: the I frame of every GOP.  Chroma of an I frame does not depend on its luma (no pixel prediction,
@@ -793,8 +807,10 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // (the room left on a CU was measured for those), and as long as a CU's share of the chroma units, at 4.5 us each, stays
         // within 0.85 of the luma step (1.67 us per wavefront step with two batches in flight) -- CIF: up to 367 frames
         const int luma_steps = g.cols8 + 2 * (g.rows8 - 1);
+        // (three batches in flight: only while they leave the CUs room, up to 2.75 luma workgroups per CU -- three ranges of 220 frames
+        //  2.03 M frames/s with the one-per-CU launch, 1.96 M without; of 250 frames 1.80 M with, 2.16 M without)
         const bool cap_ok = whole && ctx->chroma_cap && (ctx->intra_waves * 2 + 7) / 8 <= 3 &&
-                            270LL * G * cwgs <= 85LL * luma_steps * ctx->n_cu;
+                            270LL * G * cwgs <= 85LL * luma_steps * ctx->n_cu && (!three || 12LL * G <= 11LL * ctx->n_cu);
         if (NGI > 1) { if (int rc = group_streams(ctx, NGI)) return rc; }
         if (!single && !same && (joined || !lazy || ctx->st_ahead)) { if (int rc = fork_all(ctx)) return rc; }
         for (int k = 0; k < NGI; k++) {
@@ -802,7 +818,7 @@ int encode_range(icsp_ctx* ctx, int first, int n)
             hipStream_t sk = chain_stream(k);
             FrameSel fk{ first + g0, L, g1 - g0, nullptr };
             // frames in flight at once (which decides the kernel form): whole placement -> another batch like this one beside it
-            LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? 2 * G : G, sk); });
+            LT(ctx, ICSP_K_INTRA_LUMA, sk, [&] { launch_intra_luma(ctx, g, fk, b, g1 - g0, whole ? (three ? 3 : 2) * G : G, sk); });
         }
         const int sc_ = xcd_slices(G, cwgs);
         // A range placed whole runs beside another range's luma launch, and with up to about 1.4 frames per CU its chroma launches
@@ -931,6 +947,7 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
     if (int rc = second_stream(ctx)) return rc;
     if (int rc = group_streams(ctx, 2)) return rc;
     hipStream_t st = ctx->stream, s2 = ctx->stream2;
+    ctx->prev2_first = ctx->last_first; ctx->prev2_n = ctx->last_n;
     ctx->last_first = hull_first; ctx->last_n = hull_n; ctx->last_whole = 1; ctx->last_groups = 1;
     Flight* F = nullptr;
     bool same = false, joined = false;
@@ -971,6 +988,7 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
         HIPQ(hipEventRecord(F->ev_tab, st)); F->tab_up = true;
         ctx->st_ahead = true;
     }
+    ctx->rr &= 1;
     bool moved = same && F->sidx != ctx->rr;
     F->sidx = ctx->rr; ctx->rr ^= 1;
     hipStream_t cs = F->sidx ? ctx->pstream[1] : st;
@@ -1603,6 +1621,8 @@ int icsp_create(icsp_ctx_t** out, const icsp_params_t* p, int device_id, int max
     memset(ctx->flight, 0, sizeof(ctx->flight));
     ctx->last_first = 0; ctx->last_n = 0; ctx->rr = 0; ctx->single = false;
     { int v_ = 1; if (!env_int("ICSP_I_STREAM_B", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->i_stream_b = v_ != 0; }
+    { int v_ = 1; if (!env_int("ICSP_CHAINS3", 0, 1, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chains3 = v_ != 0; }
+    ctx->prev2_first = ctx->prev2_n = 0;
     { int v_ = 60; if (!env_int("ICSP_CHROMA_CAP", 0, 120, &v_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->chroma_cap = v_; }
     ctx->last_form = ctx->last_nw = ctx->last_ring = ctx->last_whole = ctx->last_groups = 0;
     { int w_ = 1; if (!env_int("ICSP_WHOLE", 0, 1, &w_)) { delete ctx; return ICSP_ERR_UNCORRECT_PARAM; } ctx->whole_ok = w_ != 0; }
@@ -2477,7 +2497,7 @@ int icsp_debug_poisoned_context(icsp_ctx_t** out)
     ctx->device = 0; ctx->slot = 0; ctx->max_frames = 1;
     memset(&ctx->g, 0, sizeof(ctx->g)); memset(&ctx->b, 0, sizeof(ctx->b)); memset(&ctx->pk, 0, sizeof(ctx->pk));
     memset(ctx->flight, 0, sizeof(ctx->flight));
-    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->i_stream_b = false; ctx->chroma_cap = 60;
+    ctx->last_first = ctx->last_n = ctx->rr = 0; ctx->whole_ok = true; ctx->single = false; ctx->prio_lo = 0; ctx->i_stream_b = false; ctx->chains3 = false; ctx->prev2_first = ctx->prev2_n = 0; ctx->chroma_cap = 60;
     ctx->stream = ctx->stream2 = nullptr; ctx->ev_fork = ctx->ev_join = nullptr; ctx->up_stream = ctx->down_stream = nullptr;
     for (int k = 0; k < kMaxPGroups; k++) { ctx->pstream[k] = nullptr; ctx->ev_pjoin[k] = nullptr; }
     ctx->d_frames = nullptr; ctx->pk_host = nullptr; ctx->pk_cap = 0; ctx->pk_first = -1; ctx->pk_n = 0; ctx->pk_total = 0;

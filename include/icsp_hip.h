@@ -40,6 +40,8 @@
  *                        chroma work per CU fits the luma step: up to about 360 CIF frames) go to one workgroup per CU that reserves
  *                        this many KB of LDS without using them, so that it stays alone on its CU beside the other range's luma
  *                        launch (default 60; 0: always the plain chroma launch)
+ *   ICSP_CHAINS3   0|1   1 (default): three all-intra ranges in rotation take three chain streams in turn (three batches in flight);
+ *                        0: two chain streams whatever the rotation
  *   ICSP_I_STREAM_B 0|1  1 (default): when the caller alternates between independent IPPP ranges, the I-frame launches of every other
  *                        range run on a stream of their own instead of following the first range's on the second stream; 0: one I stream
  *   ICSP_TIMELINE_DUMP <file>  (diagnostics) every kernel launch of the context between HIP events; "kernel stream start_us end_us"

@@ -7,7 +7,7 @@ Regimes: geometry {CIF, 352x576, 4CIF, 720p, 1088p} x batch {100 ... 3390 CIF fr
 10} x {one resident range encoded again and again, two alternating, three in rotation}.  For each regime the resident throughput
 with everything left to the library (default) and with one knob forced at a time:
 
-    all-intra: ICSP_INTRA_FORM 8 (plain wavefront) / 32, ICSP_INTRA_GROUP 2 / 1 (rows chained in pairs / the plain wavefront), ICSP_CHROMA_CAP 0, ICSP_WHOLE 0 (two ranges or more), ICSP_I_GROUPS 1 (one range)
+    all-intra: ICSP_INTRA_FORM 8 (plain wavefront) / 32, ICSP_INTRA_GROUP 2 / 1 (rows chained in pairs / the plain wavefront), ICSP_CHROMA_CAP 0, ICSP_WHOLE 0 (two ranges or more), ICSP_I_GROUPS 1 (one range), ICSP_CHAINS3 0 (three ranges)
     period 10: ICSP_P_GROUPS 1 / 2, ICSP_WHOLE 0 and ICSP_I_STREAM_B 0 (two ranges or more), ICSP_INTRA_FORM 8 / 32, ICSP_INTRA_GROUP 2 (the I step)
 
 Every setting produces the same bytes (tests/); this is about speed only.  Writes the table and a summary (worst default / best
@@ -26,7 +26,7 @@ from icspcodec_amd import capi, clipgen  # noqa: E402
 
 GEOMS = {"CIF": (352, 288), "352x576": (352, 576), "4CIF": (704, 576), "720p": (1280, 720), "1088p": (1920, 1088)}
 BATCHES = [100, 200, 250, 270, 300, 350, 400, 600, 1000, 3390]          # CIF frames' worth of macroblocks
-KNOBS_AI = [("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_INTRA_GROUP", "1"), ("ICSP_CHROMA_CAP", "0"), ("ICSP_WHOLE", "0"), ("ICSP_I_GROUPS", "1")]
+KNOBS_AI = [("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_INTRA_GROUP", "1"), ("ICSP_CHROMA_CAP", "0"), ("ICSP_WHOLE", "0"), ("ICSP_I_GROUPS", "1"), ("ICSP_CHAINS3", "0")]
 KNOBS_IP = [("ICSP_P_GROUPS", "1"), ("ICSP_P_GROUPS", "2"), ("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_I_STREAM_B", "0")]
 # --quick: (geometry, batch, period, ranges, knobs to force); from profiles/r04_sweep.json's lowest default / best ratios
 QUICK = [("CIF", 300, 0, 2, [("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "1"), ("ICSP_CHROMA_CAP", "0")]),
@@ -125,7 +125,7 @@ def main():
             continue
         qp = 8 if period else 16
         knobs = quick_knobs.get((g, b, period, r)) or [kv for kv in (KNOBS_IP if period else KNOBS_AI)
-                                                        if not (kv[0] in ("ICSP_WHOLE", "ICSP_I_STREAM_B") and r == 1) and not (kv[0] == "ICSP_I_GROUPS" and r > 1)]
+                                                        if not (kv[0] in ("ICSP_WHOLE", "ICSP_I_STREAM_B") and r == 1) and not (kv[0] == "ICSP_I_GROUPS" and r > 1) and not (kv[0] == "ICSP_CHAINS3" and r < 3)]
         try:
             dflt, choice = measure(w, h, qp, period, n, r, [], a.budget_s)
             forced = {}
