@@ -807,10 +807,13 @@ int encode_range(icsp_ctx* ctx, int first, int n)
         // (the room left on a CU was measured for those), and as long as a CU's share of the chroma units, at 4.5 us each, stays
         // within 0.85 of the luma step (1.67 us per wavefront step with two batches in flight) -- CIF: up to 367 frames
         const int luma_steps = g.cols8 + 2 * (g.rows8 - 1);
-        // (three batches in flight: only while they leave the CUs room, up to 2.75 luma workgroups per CU -- three ranges of 220 frames
-        //  2.03 M frames/s with the one-per-CU launch, 1.96 M without; of 250 frames 1.80 M with, 2.16 M without)
+        // (three batches in flight: only while they leave the CUs room, up to 2.75 luma workgroups per CU -- three CIF ranges of 220 frames
+        //  2.03 M frames/s with the one-per-CU launch, 1.96 M without; of 250 frames 1.80 M with, 2.16 M without -- and up to 2 per CU for
+        //  the longer-lived workgroups of tall frames: 352x576, three ranges of 150 / 175 / 200 frames +1 % / level / -17 % with it)
+        const bool tall = g.rows8 * 2 >= g.cols8 * 3;
         const bool cap_ok = whole && ctx->chroma_cap && (ctx->intra_waves * 2 + 7) / 8 <= 3 &&
-                            270LL * G * cwgs <= 85LL * luma_steps * ctx->n_cu && (!three || 12LL * G <= 11LL * ctx->n_cu);
+                            270LL * G * cwgs <= 85LL * luma_steps * ctx->n_cu &&
+                            (!three || (tall ? 3LL * G <= 2LL * ctx->n_cu : 12LL * G <= 11LL * ctx->n_cu));
         if (NGI > 1) { if (int rc = group_streams(ctx, NGI)) return rc; }
         if (!single && !same && (joined || !lazy || ctx->st_ahead)) { if (int rc = fork_all(ctx)) return rc; }
         for (int k = 0; k < NGI; k++) {
