@@ -78,12 +78,13 @@ def test_alternating_disjoint_ranges_without_a_sync(period, q, name_a, groups, m
     enc.close()
 
 
-@pytest.mark.parametrize("period,q,istream_b", [(0, 16, "1"), (5, 8, "1"), (5, 8, "0")])
-def test_three_ranges_in_rotation_change_streams(period, q, istream_b, monkeypatch):
-    """Three ranges over two chain streams: every range comes back on the other stream than its previous pass and has to wait
-    for that pass (ev_done) -- and, IPPP, its I frames on the other I stream (ICSP_I_STREAM_B=0: all of them on one).  Unequal
-    sizes, so that the passes really are in flight together."""
+@pytest.mark.parametrize("period,q,istream_b,chains3", [(0, 16, "1", "1"), (0, 16, "1", "0"), (5, 8, "1", "1"), (5, 8, "0", "1")])
+def test_three_ranges_in_rotation_change_streams(period, q, istream_b, chains3, monkeypatch):
+    """Three ranges in rotation.  All-intra: three chain streams in turn (ICSP_CHAINS3=0: two, every range coming back on the other
+    stream than its previous pass and waiting for that pass, ev_done).  IPPP: two chain streams, a range's I frames on the I stream of
+    its chain (ICSP_I_STREAM_B=0: all of them on one).  Unequal sizes, so that the passes really are in flight together."""
     monkeypatch.setenv("ICSP_I_STREAM_B", istream_b)
+    monkeypatch.setenv("ICSP_CHAINS3", chains3)
     sizes = [120, 35, 80]
     firsts = [0, 120, 155]
     clip = clipgen.synth_clip("hallmonitorlike", sum(sizes))
