@@ -354,10 +354,10 @@ constexpr int kMaxFlights = 4;
 // How a range is laid onto the streams is decided when its record is made and kept while it is in flight:
 //   split (whole == false): the range's GOP groups / all-intra parts on `stream` and the group streams -- best when the same
 //     range is encoded again and again, since only its own parts can run beside each other;
-//   whole: everything on ONE of the two chain streams (sidx: 0 = `stream`, 1 = pstream[1]), ranges taking turns -- best when
-//     the caller alternates between independent ranges: two whole ranges are in flight side by side instead of two halves.
-//     Calls take the two streams in turn; a range that comes back on the other stream first waits for its own previous pass
-//     (ev_done, recorded behind every whole pass), so three or more ranges in rotation load both streams evenly.
+//   whole: everything on ONE of the chain streams (sidx: 0 = `stream`, 1 = pstream[1]; 2 = pstream[2] while three all-intra ranges
+//     rotate), ranges taking turns -- best when the caller alternates between independent ranges: two (three) whole ranges are in
+//     flight side by side instead of two halves.  Calls take the streams in turn; a range that comes back on another stream first
+//     waits for its own previous pass (ev_done, recorded behind every whole pass), so ranges in rotation load the streams evenly.
 struct Flight { int first, n; bool used, whole, done_valid; int sidx; hipEvent_t ev_done; hipEvent_t ev_p1[kMaxPGroups];    // ev_p1[k]: group k's first P step of the last pass over this range is done
                 // a coalesced list of ranges (icsp_encode_resident_many): first / n are its hull; the list itself, and the slot tables of its
                 // launches ([step][GOP], compacted per step) on the device and in pinned host memory
