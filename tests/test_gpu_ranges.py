@@ -352,3 +352,33 @@ def test_streams_stay_with_the_device_for_the_next_context():
         assert np.array_equal(a[k], b[k]), k
     for f in (0, 20):
         _cmp({k: a[k][f: f + 20] for k in KEYS}, po.encode_sequence(clip[f: f + 20], W, H, 8, 8, 5, nthreads=NT), f"range at {f}: ")
+
+
+@pytest.mark.parametrize("period,q,seed", [(0, 16, 1), (0, 16, 2), (5, 8, 3), (5, 8, 4)])
+def test_random_order_of_ranges_without_a_sync(period, q, seed):
+    """Five disjoint ranges (one of them ragged) encoded in a seeded random order, no sync in between, new input for one of them half
+    way: the placement changes from call to call (split / whole on two chain streams / three chain streams in turn, I stream A / B,
+    a range coming back on another stream, the flight table running over) and every transition has to keep the order the data
+    need.  All ranges against the oracle at the end."""
+    rng = np.random.default_rng(seed)
+    L = max(period, 1)
+    sizes = [40, 25, 60, 35, 33]
+    firsts = [0, 40, 65, 125, 160]
+    assert all(f % L == 0 for f in firsts)
+    total = firsts[-1] + sizes[-1]
+    clip = clipgen.synth_clip("hallmonitorlike", total)
+    fresh = clipgen.synth_clip("coastguardlike", sizes[2])
+    enc = capi.Encoder(W, H, q, q, period, max_frames=total)
+    enc.upload(clip)
+    order = rng.integers(0, 5, 60).tolist()
+    for k, r in enumerate(order):
+        if k == 30:
+            enc.upload(fresh, first=firsts[2])                  # (an upload in the middle of everything: joins, then the streams fork again)
+            clip = clip.copy(); clip[firsts[2]: firsts[2] + sizes[2]] = fresh
+        enc.encode_resident(firsts[r], sizes[r])
+    for r in range(5):                                          # (every range at least once after the new input)
+        enc.encode_resident(firsts[r], sizes[r])
+    got = enc.download(0, total)
+    enc.close()
+    for f, s in zip(firsts, sizes):
+        _cmp({k: got[k][f: f + s] for k in KEYS}, po.encode_sequence(clip[f: f + s], W, H, q, q, period, nthreads=NT), f"range at {f}: ")
