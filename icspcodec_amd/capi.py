@@ -22,7 +22,7 @@ SYMBOLS = [
     "icsp_kernel_name", "icsp_bitstream_bound", "icsp_write_bitstream", "icsp_pack_bits", "icsp_bitstream_assemble",
     "icsp_parse_header", "icsp_parse_bitstream", "icsp_upload_syntax", "icsp_decode_resident",
     "icsp_bitstream_begin", "icsp_bitstream_header", "icsp_pack_count", "icsp_pack_into", "icsp_prepare", "icsp_bitstream_place", "icsp_bitstream_end", "icsp_host_alloc", "icsp_host_free", "icsp_host_register", "icsp_host_unregister", "icsp_host_warm", "icsp_copy_streams", "icsp_upload_sync",
-    "icsp_set_groups", "icsp_single_stream", "icsp_debug_poisoned_context", "icsp_debug_last_choice", "icsp_debug_stream_pool",
+    "icsp_set_groups", "icsp_single_stream", "icsp_debug_poisoned_context", "icsp_debug_last_choice", "icsp_debug_stream_pool", "icsp_debug_plan_turns",
     "icsp_device_pci_bus_id", "icsp_numa_node_of_pci", "icsp_device_numa_node", "icsp_numa_nodes", "icsp_numa_cpus", "icsp_parse_cpulist",
     "icsp_bind_thread_to_node", "icsp_populate_here", "icsp_chunk_device",
 ]

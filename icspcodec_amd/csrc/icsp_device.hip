@@ -731,6 +731,29 @@ int launch_p_step(icsp_ctx* ctx, const DevBufs& b, const FrameSel& fs, hipStream
     return 0;
 }
 
+// Where a call's range goes, from the calls before it alone (no device state: icsp_debug_plan_turns runs it on the CPU,
+// tests/test_turns.py).  whole: the range is disjoint from the previous call's -- the caller alternates between independent ranges;
+// three: so are this one, the previous one and the one before that, all-intra: three chain streams in turn; turn: the chain stream
+// (0 = `stream`, 1, 2 = pstream[1], pstream[2]) a whole range takes.  The state moves on as a side effect.
+struct TurnState { int last_first, last_n, prev2_first, prev2_n, rr; };
+struct Turn { bool whole, three; int turn; };
+Turn plan_turn(TurnState& t, int first, int n, int L, bool may_whole, bool chains3)
+{
+    auto apart = [](int a, int an, int b_, int bn) { return a >= b_ + bn || b_ >= a + an; };
+    Turn r{ false, false, 0 };
+    r.whole = may_whole && t.last_n > 0 && apart(first, n, t.last_first, t.last_n);
+    r.three = chains3 && r.whole && L == 1 && t.prev2_n > 0 && apart(first, n, t.prev2_first, t.prev2_n) &&
+              apart(t.last_first, t.last_n, t.prev2_first, t.prev2_n);
+    t.prev2_first = t.last_first; t.prev2_n = t.last_n;
+    t.last_first = first; t.last_n = n;
+    if (r.whole) {
+        if (!r.three) t.rr &= 1;
+        r.turn = t.rr;
+        t.rr = r.three ? (t.rr + 1) % 3 : (t.rr ^ 1);
+    }
+    return r;
+}
+
 int encode_range(icsp_ctx* ctx, int first, int n)
 {
     const Geo& g = ctx->g;
@@ -752,8 +775,6 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // A caller that alternates between independent ranges (this call's range is not the previous call's and does not touch
     // it) gets every range WHOLE on one of the two chain streams, taking turns: two whole batches side by side keep twice the
     // frames in flight that the two halves of one batch do.
-    const bool whole = !single && lazy && ctx->whole_ok && ctx->last_n > 0 && (first >= ctx->last_first + ctx->last_n || ctx->last_first >= first + n);
-    auto apart = [](int a, int an, int b_, int bn) { return a >= b_ + bn || b_ >= a + an; };
     // Three all-intra ranges in rotation (this one, the one before and the one before that pairwise disjoint): THREE chain streams in
     // turn, so that three whole batches are in flight instead of two -- with the chroma stream that makes the four streams the runtime
     // has hardware queues for.  CIF, frames/s with two chain streams -> three: three ranges of 100 / 150 / 200 / 220 frames 0.91 -> 1.03,
@@ -761,10 +782,10 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // of 75 / 150 / 300: 0.70 -> 0.95, 1.12 -> 1.46, 1.70 -> 2.10 M; 352x576 3 x 100: 0.53 -> 0.64 M, 704x576 3 x 50 / 100: 0.17 -> 0.25, 0.31 ->
     // 0.39 M, 720p 3 x 30: 58 -> 86 k, 1088p 3 x 15: 16 -> 24 k (profiles/r05_exp_chains3.txt).  Two ranges alternating stay as they were
     // (a range follows its own previous pass: two in flight is all there can be).
-    const bool three = ctx->chains3 && whole && L == 1 && ctx->prev2_n > 0 && apart(first, n, ctx->prev2_first, ctx->prev2_n) &&
-                       apart(ctx->last_first, ctx->last_n, ctx->prev2_first, ctx->prev2_n);
-    ctx->prev2_first = ctx->last_first; ctx->prev2_n = ctx->last_n;
-    ctx->last_first = first; ctx->last_n = n;
+    TurnState ts{ ctx->last_first, ctx->last_n, ctx->prev2_first, ctx->prev2_n, ctx->rr };
+    const Turn turn = plan_turn(ts, first, n, L, !single && lazy && ctx->whole_ok, ctx->chains3);
+    const bool whole = turn.whole, three = turn.three;
+    ctx->last_first = ts.last_first; ctx->last_n = ts.last_n; ctx->prev2_first = ts.prev2_first; ctx->prev2_n = ts.prev2_n; ctx->rr = ts.rr;
     int NG = ctx->p_groups;
     // keep every group's launches wide enough to be worth splitting: a dozen GOPs per group (tools/sweep_regimes.py, one CIF range
     // encoded again and again: 10 GOPs 0.358 M frames/s in one group against 0.341 M in two, 20 GOPs 0.679 / 0.656, 25 GOPs 0.762 / 0.812)
@@ -783,9 +804,8 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     bool moved = false;                                // a whole range on the other stream than its previous pass
     if (whole) {
         if (int rc = group_streams(ctx, three ? 3 : 2)) return rc;
-        if (!three) ctx->rr &= 1;
-        moved = same && F->sidx != ctx->rr;
-        F->sidx = ctx->rr; ctx->rr = three ? (ctx->rr + 1) % 3 : (ctx->rr ^ 1);               // calls take the chain streams in turn
+        moved = same && F->sidx != turn.turn;
+        F->sidx = turn.turn;                             // calls take the chain streams in turn (plan_turn)
     }
     // stream of chain / part k of this range
     auto chain_stream = [&](int k) { return whole ? (F->sidx ? ctx->pstream[F->sidx] : st) : (k == 0 ? st : ctx->pstream[k]); };
@@ -2360,6 +2380,20 @@ int icsp_single_stream(icsp_ctx_t* ctx, int on)
 // What the last icsp_encode_resident chose (bench.py puts it beside its figures, so that a line explains its own regime):
 // form of the intra luma kernel (8 / 32 lanes per block), its waves per workgroup, reconstruction through the LDS ring or not, whether the range went
 // whole onto one chain stream, GOP groups.  Any pointer may be null.
+int icsp_debug_plan_turns(int intra_period, int k, const int* firsts, const int* ns, int* whole, int* three, int* turn)
+{
+    if (k < 0 || (k > 0 && (!firsts || !ns))) return ICSP_ERR_UNENOUGH_PARAM;
+    TurnState t{ 0, 0, 0, 0, 0 };
+    const int L = intra_period > 0 ? intra_period : 1;
+    for (int i = 0; i < k; i++) {
+        const Turn r = plan_turn(t, firsts[i], ns[i], L, true, true);
+        if (whole) whole[i] = r.whole;
+        if (three) three[i] = r.three;
+        if (turn) turn[i] = r.turn;
+    }
+    return ICSP_OK;
+}
+
 int icsp_debug_stream_pool(int device_id)
 {
     if (device_id < 0) return 0;

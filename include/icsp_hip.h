@@ -166,6 +166,11 @@ int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
  * 8-lane form wrote the reconstruction through its LDS ring (0/1), range placed whole on one chain stream (0/1), GOP groups, block
  * rows of the 8-lane form's wavefront chained in groups of (4) or not (0).  Any pointer may be NULL.  For reports. */
 int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups, int* intra_row_group);
+/* Test hook, needs no device: the placement the library would give k successive icsp_encode_resident calls on ranges (firsts[i], ns[i])
+ * of a fresh context with default settings -- whole[i]: on ONE chain stream (the range is disjoint from the call before);
+ * three[i]: three chain streams in turn (all-intra, three ranges in rotation); turn[i]: which chain stream (0, 1, 2).  Any
+ * output may be NULL. */
+int icsp_debug_plan_turns(int intra_period, int k, const int* firsts, const int* ns, int* whole, int* three, int* turn);
 /* Streams idle in the pool of device `device_id` (of this process): what destroyed contexts left for the next one.  For tests. */
 int icsp_debug_stream_pool(int device_id);
 /* Test hook, needs no device: a context shell in the state a failed launch-path call leaves behind (poisoned).  Every entry
