@@ -1157,7 +1157,7 @@ const FormRule kFormRules[] = {
     { GEO_4CIF,  0, BESIDE_P_STEPS,      4,  "4CIF-class frames too wide for pairs, beside P steps (round 3's rule for the plain form)" },
     { GEO_4CIF,  0, BESIDE_P_STEPS_MANY, 4,  "as above" },
     { GEO_4CIF,  0, -1,                  16, "4CIF-class frames too wide for pairs (round 3's rule for the plain form)" },
-    { GEO_TALL, -1, BESIDE_P_STEPS,      0,  "352x576, up to 12 I frames beside P steps: pairs +2-4 % (5 / 10 / 12 I frames, one to three ranges: profiles/r05_sweep_cif_tall.json)" },
+    { GEO_TALL, -1, BESIDE_P_STEPS,      0,  "352x576, up to 12 I frames beside P steps: pairs +2-4 % (5 / 10 / 12 I frames, one to three ranges: profiles/r05_sweep.json)" },
     { GEO_TALL, -1, BESIDE_P_STEPS_MANY, 2,  "352x576, 13-25 I frames beside P steps: 32-lane +1-5 % (17 / 20 I frames); 30 / 50 I frames: pairs +2-5 %" },
     { GEO_TALL, -1, BESIDE_ALONE,        0,  "352x576, a launch on its own: pairs (50 frames +5.6 %, 100-150 +1 %, 175-200 -1.3 %, 300 and more +20 %)" },
     { GEO_TALL, -1, BESIDE_RANGE,        20, "352x576: two ranges of 125 frames 0.66 M 32-lane / 0.59 M pairs, of 175 frames 0.62 / 0.79 M; one frame per CU level" },
