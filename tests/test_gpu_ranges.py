@@ -241,7 +241,7 @@ def test_chroma_reservation_never_changes_results(cap, monkeypatch):
 
 def test_default_scheduling_is_not_far_behind_any_forced_setting():
     """tools/sweep_regimes.py --quick: in ten regimes -- the headline ones (two alternating 300-frame CIF batches, all-intra and period 10;
-    a loaded chip) and the closest calls of the committed sweep (profiles/r04_sweep.json: within 3 % everywhere) -- the library's own
+    a loaded chip) and the closest calls of the committed sweep (profiles/r05_sweep.json: within 3 % everywhere) -- the library's own
     choices must be within 12 % of the best forced knob.  A wall-clock comparison inside the correctness suite: the default
     is measured before and after the forced settings, best of three runs each, and the bound is four times the sweep's worst ratio."""
     import json

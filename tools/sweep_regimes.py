@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Is the library's default scheduling within a few percent of the best forced setting in every regime?  
 
-    sweep_regimes.py [--quick] [--out profiles/r04_sweep.json] [--budget-s 0.12]
+    sweep_regimes.py [--quick] [--out profiles/r05_sweep.json] [--budget-s 0.12]
 
 Regimes: geometry {CIF, 352x576, 4CIF, 720p, 1088p} x batch {100 ... 3390 CIF frames' worth of macroblocks} x {all-intra, period
 10} x {one resident range encoded again and again, two alternating, three in rotation}.  For each regime the resident throughput
@@ -11,8 +11,8 @@ with everything left to the library (default) and with one knob forced at a time
     period 10: ICSP_P_GROUPS 1 / 2, ICSP_WHOLE 0 and ICSP_I_STREAM_B 0 (two ranges or more), ICSP_INTRA_FORM 8 / 32, ICSP_INTRA_GROUP 2 (the I step)
 
 Every setting produces the same bytes (tests/); this is about speed only.  Writes the table and a summary (worst default / best
-ratio, the regimes below 0.97) as JSON.  --quick: ten regimes -- the headline three and the closest calls of profiles/r04_sweep.json --
-each against the knobs that came closest there, the default measured before AND after the forced settings (the -m gpu smoke test)."""
+ratio, the regimes below 0.97) as JSON.  --quick: ten regimes -- the headline ones and the closest calls of profiles/r05_sweep.json --
+each against the knobs that came closest in profiles/r05_sweep.json, the default measured before AND after the forced settings (the -m gpu smoke test)."""
 import argparse
 import json
 import os
@@ -28,17 +28,17 @@ GEOMS = {"CIF": (352, 288), "352x576": (352, 576), "4CIF": (704, 576), "720p": (
 BATCHES = [100, 200, 250, 270, 300, 350, 400, 600, 1000, 3390]          # CIF frames' worth of macroblocks
 KNOBS_AI = [("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_INTRA_GROUP", "1"), ("ICSP_CHROMA_CAP", "0"), ("ICSP_WHOLE", "0"), ("ICSP_I_GROUPS", "1"), ("ICSP_CHAINS3", "0")]
 KNOBS_IP = [("ICSP_P_GROUPS", "1"), ("ICSP_P_GROUPS", "2"), ("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "8"), ("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "2"), ("ICSP_I_STREAM_B", "0")]
-# --quick: (geometry, batch, period, ranges, knobs to force); from profiles/r04_sweep.json's lowest default / best ratios
+# --quick: (geometry, batch, period, ranges, knobs to force); the headline regimes and profiles/r05_sweep.json's lowest default / best ratios
 QUICK = [("CIF", 300, 0, 2, [("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "1"), ("ICSP_CHROMA_CAP", "0")]),
-         ("CIF", 300, 10, 2, [("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "32")]),
+         ("CIF", 300, 10, 2, [("ICSP_WHOLE", "0"), ("ICSP_INTRA_FORM", "8"), ("ICSP_I_STREAM_B", "0")]),
          ("CIF", 3390, 0, 1, [("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_GROUP", "1")]),
-         ("4CIF", 350, 10, 3, [("ICSP_INTRA_FORM", "32")]),
-         ("352x576", 100, 0, 1, [("ICSP_INTRA_FORM", "8")]),
-         ("CIF", 350, 0, 3, [("ICSP_CHROMA_CAP", "0")]),
-         ("352x576", 1000, 10, 2, [("ICSP_INTRA_FORM", "8")]),
-         ("720p", 600, 0, 2, [("ICSP_INTRA_FORM", "32")]),
-         ("CIF", 1000, 10, 2, [("ICSP_INTRA_FORM", "32"), ("ICSP_P_GROUPS", "1")]),
-         ("CIF", 270, 0, 3, [("ICSP_INTRA_FORM", "32"), ("ICSP_CHROMA_CAP", "0")])]
+         ("CIF", 300, 0, 3, [("ICSP_CHAINS3", "0"), ("ICSP_CHROMA_CAP", "0")]),
+         ("4CIF", 350, 10, 3, [("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_FORM", "8")]),
+         ("CIF", 250, 10, 3, [("ICSP_INTRA_GROUP", "2"), ("ICSP_INTRA_FORM", "32")]),
+         ("352x576", 400, 0, 3, [("ICSP_CHROMA_CAP", "0"), ("ICSP_INTRA_GROUP", "2")]),
+         ("720p", 270, 0, 3, [("ICSP_INTRA_GROUP", "1"), ("ICSP_CHAINS3", "0")]),
+         ("CIF", 1000, 10, 3, [("ICSP_INTRA_FORM", "32"), ("ICSP_P_GROUPS", "1")]),
+         ("4CIF", 1000, 10, 1, [("ICSP_INTRA_FORM", "32"), ("ICSP_INTRA_FORM", "8")])]
 _clips = {}
 
 
