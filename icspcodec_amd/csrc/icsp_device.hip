@@ -936,6 +936,22 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     return 0;
 }
 
+// The slot tables of every flight record, made once per context by its first list, OUTSIDE the flight logic (growing a
+// record's tables after its admission joined everything -- which also cleared the record just admitted -- and stalled the host).
+// Ranges start at multiples of L and are disjoint, so a list holds at most ceil(max_frames / L) GOPs: L rows of that many slots.
+int many_tables(icsp_ctx* ctx, int L)
+{
+    const int cap = L * ((ctx->max_frames + L - 1) / L);
+    for (auto& f : ctx->flight) {
+        if (f.tab_cap >= cap) continue;
+        if (hipMalloc((void**)&f.d_tab, sizeof(int) * cap) != hipSuccess || hipHostMalloc((void**)&f.h_tab, sizeof(int) * cap, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError(); ctx->err = "hipMalloc slot tables"; return ICSP_ERR_MEM_ALLOC;
+        }
+        f.tab_cap = cap;
+    }
+    return 0;
+}
+
 // Several disjoint resident ranges as ONE batch (icsp_encode_resident_many): every kernel of a step is launched once over the frames
 // of all ranges -- slot tables instead of arithmetic progressions (FrameSel::table) -- so that a host holding several short ranges
 // (chunks of different clips, the ends of GOP shards) gets the launches of one long range: four ranges of 150 CIF frames cost four
@@ -972,6 +988,7 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
     hipStream_t st = ctx->stream, s2 = ctx->stream2;
     ctx->prev2_first = ctx->last_first; ctx->prev2_n = ctx->last_n;
     ctx->last_first = hull_first; ctx->last_n = hull_n; ctx->last_whole = 1; ctx->last_groups = 1;
+    if (int rc = many_tables(ctx, L)) return rc;
     Flight* F = nullptr;
     bool same = false, joined = false;
     std::vector<int> flat;
@@ -985,19 +1002,7 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
         F->many_list = nl; F->many_k = (int)rs.size();
         for (size_t r = 0; r < rs.size(); r++) { nl[2 * r] = rs[r].first; nl[2 * r + 1] = rs[r].second; }
         const int need = L * G;
-        if (need > F->tab_cap) {
-            if (int rc = join_all(ctx)) return rc;                      // (launches of an earlier list may still read the old tables)
-            HIPCHK(hipStreamSynchronize(st));
-            if (F->d_tab) (void)hipFree(F->d_tab);
-            if (F->h_tab) (void)hipHostFree(F->h_tab);
-            F->d_tab = F->h_tab = nullptr; F->tab_cap = 0;
-            const int cap = need + need / 2 + 64;
-            if (hipMalloc((void**)&F->d_tab, sizeof(int) * cap) != hipSuccess || hipHostMalloc((void**)&F->h_tab, sizeof(int) * cap, hipHostMallocDefault) != hipSuccess) {
-                (void)hipGetLastError(); ctx->err = "hipMalloc slot tables"; return ICSP_ERR_MEM_ALLOC;
-            }
-            F->tab_cap = cap;
-            joined = true;
-        }
+        if (need > F->tab_cap) { ctx->err = "slot tables: a list needs more rows than max_frames allows"; return ICSP_ERR_RANGE; }     // (cannot happen: many_tables)
         // h_tab is about to be overwritten: its last upload must have left it (the device side is ordered by the join that every
         // reuse of a record for another list goes through)
         if (F->tab_up) { HIPCHK(hipEventSynchronize(F->ev_tab)); F->tab_up = false; }

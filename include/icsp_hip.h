@@ -131,7 +131,8 @@ int icsp_encode_resident(icsp_ctx_t* ctx, int first_frame, int n);
  * progressions), so several short ranges -- chunks of different clips, the ends of GOP shards: the reference's independent GOP jobs,
  * ICSP_thread.cpp:47-56 -- cost what one long range costs (four ranges of 150 CIF frames, all-intra: 1.0 M frames/s one by one).
  * Same results as icsp_encode_resident on each range; asynchronous in the same way.  The same LIST encoded again follows its own previous
- * pass; a list whose hull touches a range still in flight waits for everything. */
+ * pass; overlap with what is still in flight is decided range by range: a list one of whose RANGES partly overlaps a range in flight
+ * waits for everything, a list whose ranges merely interleave with those of another list or range does not. */
 int icsp_encode_resident_many(icsp_ctx_t* ctx, int k, const int* first_frames, const int* ns);
 int icsp_sync(icsp_ctx_t* ctx);
 int icsp_download(icsp_ctx_t* ctx, int first_frame, int n,
@@ -164,7 +165,7 @@ int icsp_debug_keep_coef(icsp_ctx_t* ctx, int on);
 int icsp_download_coef(icsp_ctx_t* ctx, int first_frame, int n, double* coef);
 /* What the last icsp_encode_resident chose: intra luma kernel form (8 or 32 lanes per block), its waves per workgroup, whether the
  * 8-lane form wrote the reconstruction through its LDS ring (0/1), range placed whole on one chain stream (0/1), GOP groups, block
- * rows of the 8-lane form's wavefront chained in groups of (4) or not (0).  Any pointer may be NULL.  For reports. */
+ * rows of the 8-lane form's wavefront chained in pairs (2) or not (0).  Any pointer may be NULL.  For reports. */
 int icsp_debug_last_choice(icsp_ctx_t* ctx, int* intra_form, int* intra_waves, int* intra_recon_ring, int* whole_range, int* gop_groups, int* intra_row_group);
 /* Test hook, needs no device: the placement the library would give k successive icsp_encode_resident calls on ranges (firsts[i], ns[i])
  * of a fresh context with default settings -- whole[i]: on ONE chain stream (the range is disjoint from the call before);

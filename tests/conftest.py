@@ -12,6 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: a wall-clock bound inside the GPU suite (retried once; -m gpu selects it, -m 'gpu and not perf' skips it)")
     config.addinivalue_line("markers", "ref: needs oracle/_ref built from /root/reference (skipped elsewhere)")
 
 

@@ -15,7 +15,7 @@ for l in open(bench_json):
     if l.startswith("{") and '"metric"' in l:
         line = json.loads(l)
 steps, warmup = line["steps"], line["warmup"]
-repeats = line.get("repeats", {}).get("repeats", 1)
+repeats = line.get("n_repeats") or (line.get("repeats") or {}).get("repeats", 1)      # compact line (round 6) / the one long line of rounds 1-5
 SETTLE = 100
 P, NMB = 352 * 288, 396
 BYTES = 300 * (4 * P + 8 * NMB)

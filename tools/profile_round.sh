@@ -8,6 +8,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
+export ICSP_BENCH_DETAIL=$OUT/bench_detail_profiled.json
 rocprofv3 --kernel-trace --stats -d $OUT/stats --output-format csv -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu --legs ippp > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
 # how the dominant kernel's launches overlap in the timed regions of that run (the chip-level figure of the bench line)
 python3 $R/tools/overlap_summary.py $OUT/stats $OUT/bench_profiled.json $OUT/overlap.json > $OUT/overlap.txt 2>&1
