@@ -10,7 +10,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
-namespace icspk {
+namespace icspk __attribute__((visibility("hidden"))) {     // internal to libicsp_hip.so: not exported
 
 // ------------------------------------------------------------------------------------------------ kernel arguments
 struct Geo {

@@ -22,37 +22,14 @@
  * Errors: every function returns 0 (= reference SUCCESS, ICSP_Codec_Encoder.h:33-39) or a positive
  * icsp_status code; nothing calls exit().  There is NO CPU fallback: without a usable HIP device
  * icsp_create fails with ICSP_ERR_NO_DEVICE.
- * Environment (read once by icsp_create; meant for tests and tuning, results are identical in every setting; a value
- * that is not a whole number in the stated range makes icsp_create fail with ICSP_ERR_UNCORRECT_PARAM):
- *   ICSP_NO_FUSE   0|1   1: a P step's four-state motion search and the per-frame serial kernel run as two launches instead of one
- *   ICSP_P_GROUPS  1..3  number of GOP groups whose P-step kernel chains run on separate streams (default 2)
+ * Environment: three variables a host may want (read once by icsp_create; results are identical in every setting; a value that is
+ * not a whole number in the stated range makes icsp_create fail with ICSP_ERR_UNCORRECT_PARAM):
+ *   ICSP_P_GROUPS  1..3  GOP groups whose P-step kernel chains run on separate streams (default 2; per context: icsp_set_groups)
  *   ICSP_I_GROUPS  1..2  parts (launches on separate streams) an all-intra batch of more frames than CUs is encoded in (default 2)
- *   ICSP_INTRA_FORM 8|32 lanes per 8x8 block in the intra luma kernel: 32 = latency form (two blocks per wave), 8 = throughput
- *                        form (eight blocks per wave); default: by frames in flight per CU and geometry class -- 32 while every
- *                        frame has a CU of its own, 8 above (the rule table kFormRules in icsp_device.hip, profiles/r05_sweep.json)
- *   ICSP_INTRA_GROUP 0|1|2  8-lane intra kernel: 2 = block rows run one wavefront step apart in pairs (96 steps per CIF frame instead
- *                        of 114, four waves; frames whose widest step fits eight waves), 1 = two steps apart throughout (the plain
- *                        wavefront: what 720p / 1088p frames take anyway), 0 (default) = pairs wherever they can be built
- *   ICSP_SERIAL_PRIO 0|1 1 (default): the DC-chain waves of the per-frame serial kernel run at raised issue priority
- *   ICSP_SERIAL_BANDS 0|1 1 (default): frames taller than 512 lines run the bands of their DC chains as waves of one continued wavefront
- *   ICSP_WHOLE     0|1   0: never place a range whole on one stream when the caller alternates between independent ranges
- *   ICSP_CHROMA_CAP 0..120  the all-intra chroma blocks of a range placed whole (CIF-class frames in the 8-lane luma form, batches whose
- *                        chroma work per CU fits the luma step: up to about 360 CIF frames) go to one workgroup per CU that reserves
- *                        this many KB of LDS without using them, so that it stays alone on its CU beside the other range's luma
- *                        launch (default 60; 0: always the plain chroma launch)
- *   ICSP_CHAINS3   0|1   1 (default): three all-intra ranges in rotation take three chain streams in turn (three batches in flight);
- *                        0: two chain streams whatever the rotation
- *   ICSP_I_STREAM_B 0|1  1 (default): when the caller alternates between independent IPPP ranges, the I-frame launches of every other
- *                        range run on a stream of their own instead of following the first range's on the second stream; 0: one I stream
- *   ICSP_TIMELINE_DUMP <file>  (diagnostics) every kernel launch of the context between HIP events; "kernel stream start_us end_us"
- *                        lines, against one base event, appended to <file> whenever results are collected (tools/timeline_events.py).
- *                        Costs the host two event records per launch
  *   ICSP_FAKE_DEVICES 2..64 (test hook, read once per process) the library presents that many devices, device d being physical device
- *                        d mod (real devices) with per-device records of its own (search tables, shared transfer streams, turns):
- *                        the multi-device paths of a host run on a one-GPU box
- *   ICSP_QUANT_POW2 0|1  1 (default): quantiser steps that are both powers of two take the add / multiply / truncate form of the
- *                        quantiser in the 8-lane transform chain (oracle/fma_proof.c); 0: the multiply-high division for every step
- *   ICSP_XCD_SLICES 0..64 bands a frame is cut into when a P step's workgroups are dealt over the XCDs (0 = automatic; rounded down to a power of two)
+ *                        d mod (real devices) with per-device records of its own: the multi-device paths of a host on a one-GPU box
+ * The tuning and diagnostic overrides the kernels' authors use (ICSP_INTRA_FORM, ICSP_CHROMA_CAP, ICSP_TIMELINE_DUMP ...) are listed in
+ * INTEGRATION.md ("Tuning and diagnostic overrides"); none of them changes a result either.
  * Launch path: a failed kernel launch, event record or cross-stream wait could silently drop an ordering edge and yield
  * wrong bits, so it POISONS the context: that call and every later call on the context return ICSP_ERR_HIP
  * (icsp_last_error names the first failure) until icsp_destroy.

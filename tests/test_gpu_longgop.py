@@ -168,7 +168,7 @@ def test_four_contexts_share_one_device_flagged():
                                                     ("staticlike", 24, 16, 2, 2), ("stefanlike", 33, 8, 3, 2)])
 def test_back_to_back_passes_of_one_range_overlap(name, n, q, period, groups, monkeypatch):
     """encode_range called again and again on the same resident range without a sync in between: the I frames of pass N+1 run
-    beside P steps 2.. of pass N (icsp_device.hip, encode_range).  Ragged ends (a last GOP that stops before, at, or after its
+    beside P steps 2.. of pass N (icsp_sched.cpp, encode_range).  Ragged ends (a last GOP that stops before, at, or after its
     first P frame; a lone I frame), one and two GOP groups; then a different range, an upload and a last pass."""
     monkeypatch.setenv("ICSP_P_GROUPS", str(groups))
     clip = clipgen.synth_clip(name, n)

@@ -1,4 +1,4 @@
-"""Encodes of independent ranges of ONE context are not ordered against each other (icsp_device.hip: flight_admit /
+"""Encodes of independent ranges of ONE context are not ordered against each other (icsp_sched.cpp: flight_admit /
 encode_range): the next chunk of a clip -- closed GOPs and independent I frames are the reference's independent jobs,
 ICSP_Codec_Encoder_source.cpp:186-213 -- starts beside the one before it; the same range again follows its own previous
 pass stream by stream; a range that partly overlaps one in flight joins everything first.  No host synchronisation between

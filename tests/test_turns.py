@@ -1,4 +1,4 @@
-"""Which chain stream a call's range goes to, from the sequence of calls alone (plan_turn in icsp_device.hip, run on the CPU through the
+"""Which chain stream a call's range goes to, from the sequence of calls alone (plan_turn in icsp_sched.cpp, run on the CPU through the
 test hook icsp_debug_plan_turns): the properties the resident regimes rest on."""
 import ctypes as C
 

@@ -1,7 +1,7 @@
 """The block wavefront of the intra luma kernels as a model on the CPU: which (step, wave, lane group) takes which 8x8 block, for the
 plain wavefront t = c8 + 2 r8 and for block rows chained in groups of GC (t = c8 + r8 + r8 / GC), with the slots of a step rotating
 over the waves.  The formulas are those of k_intra_luma8<NW, RING, GC> (icspcodec_amd/csrc/icsp_blk8.hip.inc) and of
-intra_slots / intra_waves_chained (icsp_device.hip) restated; the test checks the properties the kernel's correctness rests on,
+intra_slots / intra_waves_chained (icsp_sched.cpp) restated; the test checks the properties the kernel's correctness rests on,
 for the geometries of the GPU parity suite:
 
   * every block is taken exactly once, by an active lane group, inside the frame;

@@ -1,6 +1,7 @@
 // Diagnostic build of the intra kernel with in-kernel cycle stamps (s_memtime) — never part of the product.
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -DICSP_DIAG -Iinclude -o /tmp/diag_intra tools/diag_intra.hip icspcodec_amd/csrc/icsp_bitstream.cpp
 #include "../icspcodec_amd/csrc/icsp_device.hip"
+#include "../icspcodec_amd/csrc/icsp_sched.cpp"      // (the host half: contexts, scheduling, the C ABI)
 #include <vector>
 #include <cstdlib>
 int main(int argc, char** argv)

@@ -2,6 +2,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -DICSP_DIAG8 -Iinclude -o tools/diag_intra8.bin tools/diag_intra8.hip icspcodec_amd/csrc/icsp_bitstream.cpp icspcodec_amd/csrc/icsp_topology.cpp
 //   ICSP_INTRA_FORM=8 tools/diag_intra8.bin [frames per range] [ranges alternating]
 #include "../icspcodec_amd/csrc/icsp_device.hip"
+#include "../icspcodec_amd/csrc/icsp_sched.cpp"      // (the host half: contexts, scheduling, the C ABI)
 #include <vector>
 #include <cstdlib>
 int main(int argc, char** argv)

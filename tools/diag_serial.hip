@@ -1,6 +1,7 @@
 // Diagnostic build: cycle stamps inside k_frame_serial (never part of the product).
 //   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -DICSP_DIAG -DICSP_DIAG_SERIAL -Iinclude -o tools/diag_serial.bin tools/diag_serial.hip icspcodec_amd/csrc/icsp_bitstream.cpp
 #include "../icspcodec_amd/csrc/icsp_device.hip"
+#include "../icspcodec_amd/csrc/icsp_sched.cpp"      // (the host half: contexts, scheduling, the C ABI)
 #include <vector>
 #include <cstdlib>
 int main()

@@ -3,6 +3,7 @@
 // One line per (kernel, GOP group): workgroups, first/last start, first/last end (us from the earliest record; s_memrealtime,
 // 100 MHz), median and maximum workgroup duration.
 #include "../icspcodec_amd/csrc/icsp_device.hip"
+#include "../icspcodec_amd/csrc/icsp_sched.cpp"      // (the host half: contexts, scheduling, the C ABI)
 #include <algorithm>
 #include <vector>
 int main(int argc, char** argv)
