@@ -120,6 +120,38 @@ def cpu_baseline():
     return port
 
 
+# ------------------------------------------------------------------------------------------------ issue model
+# What a vector wave-instruction costs a SIMD's issue port, by class, measured by wall clock with 2-4 waves on the SIMD
+# (tools/probe_issue_waves.hip -> profiles/r06_probe_issue_waves.txt, condensed in profiles/issue_costs.json).
+# fp64 add / mul / fma, conversions and the "quarter-rate" 32-bit instructions (v_sad_u8, DPP moves, v_med3, multiplies) hold the
+# port about 4.3 cycles; simple integer instructions (add, and, shifts, compares, selects) 2.3 cycles in a stream of their own, but
+# about 3.7 between fp64 instructions (the 50/50 mixes): `simple_int_mixed` is what the codec's kernels see, `simple_int_pure` the best case.
+ISSUE_COSTS_DEFAULT = {"ns": {"fp64": 1.80, "cvt": 1.80, "other": 1.76, "simple_int_mixed": 1.55, "simple_int_pure": 0.95},
+                       "simple_share_of_rest": 0.85, "cvt_share_default": 0.07}
+
+
+def issue_costs():
+    try:
+        c = json.load(open(os.path.join(ROOT, "profiles", "issue_costs.json")))
+        return {"ns": dict(ISSUE_COSTS_DEFAULT["ns"], **c.get("ns", {})), "simple_share_of_rest": c.get("simple_share_of_rest", 0.85),
+                "cvt_share_default": c.get("cvt_share_default", 0.07)}
+    except Exception:
+        return ISSUE_COSTS_DEFAULT
+
+
+def issue_seconds(total, fp64, cvt=None, n_simd=1024, best_case=False):
+    """Seconds the chip's SIMDs need to ISSUE `total` vector wave-instructions of which `fp64` are fp64 add / mul / fma and `cvt`
+    conversions (None: the default share); the rest split into simple integer and quarter-rate instructions by the static census of
+    the kernels (profiles/issue_costs.json)."""
+    c = issue_costs()
+    ns = c["ns"]
+    cvt = c["cvt_share_default"] * total if cvt is None else cvt
+    rest = max(0.0, total - fp64 - cvt)
+    simple = rest * c["simple_share_of_rest"]
+    t = fp64 * ns["fp64"] + cvt * ns["cvt"] + (rest - simple) * ns["other"] + simple * (ns["simple_int_pure"] if best_case else ns["simple_int_mixed"])
+    return t * 1e-9 / n_simd
+
+
 # ------------------------------------------------------------------------------------------------ output
 DETAIL_PATH = os.environ.get("ICSP_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
 LINE_LIMIT = 8192              # bytes of the final stdout line (VERDICT r05: the driver could not parse a 21 KB line)
@@ -350,15 +382,18 @@ def main():
         if choice is not None and e.get("choice") and any(choice.get(k) != v for k, v in e["choice"].items()):
             return {"skipped": "this run chose other kernel forms than the counted run", "counted_choice": e["choice"], "this_choice": choice}
         vi, f64 = e.get("valu_insts_per_pass", 0), e.get("fp64_valu_insts_per_pass", 0)
-        out = {"valu_issue_frac": round(vi / ranks / sec_per_pass / ISSUE_PEAK, 4),
+        out = {"valu_issue_frac": round(issue_seconds(vi / ranks, f64 / ranks, n_simd=4 * n_cu_dev) / sec_per_pass, 4),
+               "valu_issue_frac_uniform_4_cycles": round(vi / ranks / sec_per_pass / ISSUE_PEAK, 4),
                "fp64_valu_frac": round(f64 / ranks * 64 / sec_per_pass / 1e9 / FP64_VALU_PEAK_GOPS, 4),
                "waiting_share_of_wave_cycles": e.get("waiting_share_of_wave_cycles"),
                "valu_insts_per_pass": int(vi), "hbm_bytes_per_pass": e.get("hbm_bytes_per_pass"),
                "traffic_over_algorithmic": e.get("traffic_over_algorithmic"),
                "by_kernel": e.get("by_kernel"),
                "source": e.get("source"),
-               "is": "vector wave-instructions of one pass / time per pass of THIS run / (1024 SIMDs x 2.4 GHz / 4): the share of "
-                     "the chip's vector issue slots the leg fills -- the ceiling that binds these kernels (DESIGN.md section 5)"}
+               "is": "time the chip's SIMDs need to issue the vector wave-instructions of one pass, at the per-class costs measured by "
+                     "tools/probe_issue_waves.hip (profiles/issue_costs.json), over this run's time per pass: the share of the chip's vector "
+                     "issue time the leg fills -- the ceiling that binds these kernels (DESIGN.md section 5); *_uniform_4_cycles: rounds "
+                     "4-5's model, every instruction 4 cycles at 2.4 GHz"}
         return out
 
     def timed(enc, n, steps, warmup, dominant, alternate=True, ranges=2):
@@ -922,7 +957,11 @@ def main():
         vi = pmc.get("valu_insts_per_launch")
         if vi:
             peak = 256 * 4 * 2.4e9 / 4                        # 256 CUs x 4 SIMDs, one wave-instruction per 4 cycles at 2.4 GHz
-            roof["valu_issue_frac"] = round(vi * lps / (step_ms * 1e-3) / peak, 4)
+            # conversions of one 300-frame launch of the luma kernel (counted), None when the counter file has none
+            cvt_l = next((v.get("SQ_INSTS_VALU_CVT") for k, v in (_tj.get("kernels") or {}).items()
+                          if k.startswith("k_intra_luma8") and v.get("frames_per_launch") == NFRAMES), None)
+            roof["valu_issue_frac"] = round(issue_seconds(vi * lps, (ops or 0) * lps, cvt_l * lps if cvt_l else None, n_simd=4 * n_cu_dev) / (step_ms * 1e-3), 4)
+            roof["valu_issue_frac_uniform_4_cycles"] = round(vi * lps / (step_ms * 1e-3) / peak, 4)
             roof["valu_insts_per_launch"] = int(vi)
             roof["waiting_share_of_wave_cycles"] = pmc.get("waiting_share_of_wave_cycles")
             roof["valu_issue_peak_Ginst"] = round(peak / 1e9, 1)
@@ -943,18 +982,29 @@ def main():
             insts_frame = (vi + chroma_vi) / NFRAMES if chroma_vi else vi * 1.5 / NFRAMES
             f64_frame = ((ops or 0) + chroma_f64) / NFRAMES if chroma_f64 else (ops or 0) * 1.5 / NFRAMES
             fps_gpu = fps / world
+            nsimd = 4 * n_cu_dev
+            cvt_frame = (cvt_l / NFRAMES * (insts_frame * NFRAMES / vi)) if cvt_l else None       # (the luma kernel's share, scaled to the step's kernels)
+            t_frame = issue_seconds(insts_frame, f64_frame, cvt_frame, nsimd)                     # seconds of chip issue time per frame, as the kernels' mixes run
+            t_best = issue_seconds(insts_frame, f64_frame, cvt_frame, nsimd, best_case=True)      # ... if every simple integer instruction issued at its 2-cycle rate
+            t_floor = issue_seconds(f64_frame, f64_frame, 0.0, nsimd)
             roof["binding"] = {
-                "resource": "valu_issue", "frac": round(insts_frame * fps_gpu / peak, 4),
+                "resource": "valu_issue", "frac": round(fps_gpu * t_frame, 4),
                 "valu_insts_per_frame": int(insts_frame), "fp64_floor_insts_per_frame": int(f64_frame),
-                "ceiling_fps_at_current_insts": round(peak / insts_frame, 1), "ceiling_fps_at_fp64_floor": round(peak / f64_frame, 1) if f64_frame else None,
-                "value_over_ceiling_at_current_insts": round(fps_gpu * insts_frame / peak, 4),
-                "value_over_ceiling_at_fp64_floor": round(fps_gpu * f64_frame / peak, 4) if f64_frame else None,
+                "ceiling_fps_at_current_insts": round(1.0 / t_frame, 1), "ceiling_fps_at_current_insts_best_case": round(1.0 / t_best, 1),
+                "ceiling_fps_at_fp64_floor": round(1.0 / t_floor, 1) if f64_frame else None,
+                "ceiling_fps_uniform_4_cycles": round(peak / insts_frame, 1),
+                "value_over_ceiling_at_current_insts": round(fps_gpu * t_frame, 4),
+                "value_over_ceiling_at_fp64_floor": round(fps_gpu * t_floor, 4) if f64_frame else None,
+                "issue_ns_per_class": issue_costs()["ns"],
                 "chroma_kernels": "counted" if chroma_vi else "luma kernel x 1.5 (no counted chroma launches in profiles/traffic.json)",
                 "is": "vector wave-instructions per frame of this leg (luma kernel + the step's chroma kernels, rocprofv3 SQ counters in "
-                      "profiles/traffic.json) against the chip's vector issue rate (1024 SIMDs x 2.4 GHz / 4): `frac` of the issue slots "
-                      "are filled; at today's instruction count the chip could do ceiling_fps_at_current_insts frames/s, with nothing but the "
-                      "bit-exact fp64 arithmetic left ceiling_fps_at_fp64_floor.  The HBM figures above stay the contract's; this is the "
-                      "ceiling that binds (DESIGN.md section 5)"}
+                      "profiles/traffic.json) priced per class at what a SIMD's issue port was MEASURED to sustain with 2-4 waves on it "
+                      "(tools/probe_issue_waves.hip, profiles/r06_probe_issue_waves.txt: fp64 / conversions / quarter-rate 32-bit about 4.3 "
+                      "cycles, simple integer 2.3 cycles alone and about 3.7 between fp64 instructions): `frac` of the chip's issue time is "
+                      "filled; at today's instruction count the chip could do ceiling_fps_at_current_insts frames/s (…_best_case: simple "
+                      "integer instructions at their 2-cycle rate throughout; …_uniform_4_cycles: rounds 4-5's model), with nothing but "
+                      "the bit-exact fp64 arithmetic left ceiling_fps_at_fp64_floor.  The HBM figures above stay the contract's; this is "
+                      "the ceiling that binds (DESIGN.md section 5)"}
     line = {
         "metric": "CIF encode fps, resident encode loop (all-intra QP=16; IPPP and the 8-GPU workloads alongside)", "value": round(fps, 1),
         "unit": "frames/s", "n_gpus": world, "ranks_seen": ranks_seen, "steps": a.steps, "warmup": a.warmup,

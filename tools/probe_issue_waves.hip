@@ -25,7 +25,11 @@
              asm volatile(ASMA : "+v"(r[4]) : C); asm volatile(ASMB : "+v"(ri[4]) : "v"(ci)); asm volatile(ASMA : "+v"(r[5]) : C); asm volatile(ASMB : "+v"(ri[5]) : "v"(ci)); \
              asm volatile(ASMA : "+v"(r[6]) : C); asm volatile(ASMB : "+v"(ri[6]) : "v"(ci)); asm volatile(ASMA : "+v"(r[7]) : C); asm volatile(ASMB : "+v"(ri[7]) : "v"(ci));) }
 
-constexpr int NT = 17;
+constexpr int NT = 21;
+#define OPD(ASM, j) asm volatile(ASM : "+v"(r[j]) : "v"(c));
+#define OPI(ASM, j) asm volatile(ASM : "+v"(ri[j]) : "v"(ci));
+#define AF "v_add_f64 %0, %0, %1"
+#define AI "v_add_u32 %0, %0, %1"
 template <int T> __global__ void k(long long* out, int iters, double c, int ci, float cf)
 {
     extern __shared__ unsigned char lds[];
@@ -51,6 +55,20 @@ template <int T> __global__ void k(long long* out, int iters, double c, int ci, 
     if (T == 14) { int* r = ri; BODY("v_med3_i32 %0, %0, %1, %1", "v"(ci)) }
     if (T == 15) { int* r = ri; BODY("v_mul_hi_u32 %0, %0, %1", "v"(ci)) }
     if (T == 16) { int* r = ri; BODY("v_cmp_gt_i32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc", "v"(ci)) }      // two instructions per slot
+    // simple integer instructions of four kinds in turn
+    if (T == 17) { for (int it = 0; it < iters; it++) { REP4(OPI(AI, 0) OPI("v_and_b32 %0, %0, %1", 1) OPI("v_lshlrev_b32 %0, 1, %0", 2) OPI("v_xor_b32 %0, %0, %1", 3)
+                   OPI(AI, 4) OPI("v_and_b32 %0, %0, %1", 5) OPI("v_lshlrev_b32 %0, 1, %0", 6) OPI("v_xor_b32 %0, %0, %1", 7) OPI(AI, 8) OPI("v_and_b32 %0, %0, %1", 9)
+                   OPI("v_lshlrev_b32 %0, 1, %0", 10) OPI("v_xor_b32 %0, %0, %1", 11) OPI(AI, 12) OPI("v_and_b32 %0, %0, %1", 13) OPI("v_lshlrev_b32 %0, 1, %0", 14) OPI("v_xor_b32 %0, %0, %1", 15)) } }
+    // v_add_u32 and v_sad_u8 in turn
+    if (T == 18) { for (int it = 0; it < iters; it++) { REP4(OPI(AI, 0) OPI("v_sad_u8 %0, %0, %1, %0", 1) OPI(AI, 2) OPI("v_sad_u8 %0, %0, %1, %0", 3) OPI(AI, 4) OPI("v_sad_u8 %0, %0, %1, %0", 5)
+                   OPI(AI, 6) OPI("v_sad_u8 %0, %0, %1, %0", 7) OPI(AI, 8) OPI("v_sad_u8 %0, %0, %1, %0", 9) OPI(AI, 10) OPI("v_sad_u8 %0, %0, %1, %0", 11) OPI(AI, 12) OPI("v_sad_u8 %0, %0, %1, %0", 13)
+                   OPI(AI, 14) OPI("v_sad_u8 %0, %0, %1, %0", 15)) } }
+    // one fp64 add in four (three v_add_u32 between)
+    if (T == 19) { for (int it = 0; it < iters; it++) { REP4(OPD(AF, 0) OPI(AI, 1) OPI(AI, 2) OPI(AI, 3) OPD(AF, 4) OPI(AI, 5) OPI(AI, 6) OPI(AI, 7) OPD(AF, 8) OPI(AI, 9) OPI(AI, 10) OPI(AI, 11)
+                   OPD(AF, 12) OPI(AI, 13) OPI(AI, 14) OPI(AI, 15)) } }
+    // three fp64 adds in four
+    if (T == 20) { for (int it = 0; it < iters; it++) { REP4(OPD(AF, 0) OPD(AF, 1) OPD(AF, 2) OPI(AI, 3) OPD(AF, 4) OPD(AF, 5) OPD(AF, 6) OPI(AI, 7) OPD(AF, 8) OPD(AF, 9) OPD(AF, 10) OPI(AI, 11)
+                   OPD(AF, 12) OPD(AF, 13) OPD(AF, 14) OPI(AI, 15)) } }
     const long long t1 = __builtin_amdgcn_s_memtime(), w1 = __builtin_amdgcn_s_memrealtime();
     double s = 0; int si = 0; float sf = 0;
     for (int j = 0; j < 16; j++) { s += r[j]; si += ri[j]; sf += rf[j]; }
@@ -94,11 +112,14 @@ template <int T> void all(long long* d, long long* h, const char* name, int per_
 int main()
 {
     long long *d, *h = (long long*)malloc(64); hipMalloc(&d, 64);
-    printf("per WAVE-INSTRUCTION ON ONE SIMD: wall ns (HIP events, 256 workgroups, one per CU) | s_memtime ticks (clock = ticks / s_memrealtime)\n");
+    printf("per WAVE-INSTRUCTION ON ONE SIMD: wall ns (HIP events, 256 workgroups, one per CU) = what the SIMD sustains | s_memtime ticks of WAVE 0 alone\n"
+           "(the oldest wave of its SIMD keeps its own rate whatever runs beside it: issue goes by age) (clock = ticks / s_memrealtime)\n");
     all<0>(d, h, "v_add_u32", 1); all<1>(d, h, "v_and_b32", 1); all<2>(d, h, "v_cndmask_b32 (vcc)", 1); all<3>(d, h, "v_mul_i32_i24", 1);
     all<11>(d, h, "v_fma_f32", 1); all<12>(d, h, "v_sad_u8", 1); all<13>(d, h, "v_mov_b32_dpp row_shr", 1); all<14>(d, h, "v_med3_i32", 1);
     all<15>(d, h, "v_mul_hi_u32", 1); all<16>(d, h, "v_cmp + v_cndmask (per instruction)", 2);
     all<4>(d, h, "v_add_f64", 1); all<5>(d, h, "v_mul_f64", 1); all<6>(d, h, "v_fma_f64", 1); all<7>(d, h, "v_cvt_f64_i32", 1); all<8>(d, h, "v_cvt_i32_f64", 1);
     all<9>(d, h, "mix 50/50 v_add_f64 + v_add_u32", 1); all<10>(d, h, "mix 50/50 v_fma_f64 + v_and_b32", 1);
+    all<19>(d, h, "mix 25/75 v_add_f64 + v_add_u32", 1); all<20>(d, h, "mix 75/25 v_add_f64 + v_add_u32", 1);
+    all<17>(d, h, "simple ints: add, and, lshl, xor", 1); all<18>(d, h, "mix 50/50 v_add_u32 + v_sad_u8", 1);
     return 0;
 }
