@@ -183,7 +183,8 @@ def compact_line(full):
     if roof.get("chip_level"):
         r["chip_level"] = _pick(roof["chip_level"], ("achieved", "frac"))
     if roof.get("binding"):
-        r["binding"] = {k: v for k, v in roof["binding"].items() if not isinstance(v, (str, dict, list)) or k == "resource"}
+        r["binding"] = {k: v for k, v in roof["binding"].items()
+                        if (not isinstance(v, (str, dict, list)) or k == "resource") and k not in ("ceiling_fps_at_current_insts_best_case", "ceiling_fps_uniform_4_cycles")}
     cpu = full.get("cpu_baseline")
     c = None
     if cpu:
@@ -1001,8 +1002,9 @@ def main():
                       "profiles/traffic.json) priced per class at what a SIMD's issue port was MEASURED to sustain with 2-4 waves on it "
                       "(tools/probe_issue_waves.hip, profiles/r06_probe_issue_waves.txt: fp64 / conversions / quarter-rate 32-bit about 4.3 "
                       "cycles, simple integer 2.3 cycles alone and about 3.7 between fp64 instructions): `frac` of the chip's issue time is "
-                      "filled; at today's instruction count the chip could do ceiling_fps_at_current_insts frames/s (…_best_case: simple "
-                      "integer instructions at their 2-cycle rate throughout; …_uniform_4_cycles: rounds 4-5's model), with nothing but "
+                      "filled; at today's instruction count the chip could do ceiling_fps_at_current_insts frames/s (…_best_case: every simple "
+                      "integer instruction at the 2.3 cycles that only a stream of ONE opcode reaches -- no mixed stream does; "
+                      "…_uniform_4_cycles: rounds 4-5's model), with nothing but "
                       "the bit-exact fp64 arithmetic left ceiling_fps_at_fp64_floor.  The HBM figures above stay the contract's; this is "
                       "the ceiling that binds (DESIGN.md section 5)"}
     line = {

@@ -311,48 +311,6 @@ __global__ __launch_bounds__(256) void k_chroma_dc(Geo g, FrameSel fs, DevBufs b
     for (int n = threadIdx.x; n < nblk; n += 256) b.dcpred[(fb + n) * 6 + 4 + pl] = s_sp[n];
 }
 
-// The same with every WAVE of the workgroup walking the chain of a (frame, plane) of its own (in k_chroma_dc three
-// waves of four sit at the barrier while one walks 56 steps, and their wave slots are what a loaded CU is short of): a wave sums the
-// blocks of its plane (four 8-byte loads in flight), walks the chain, writes the predictors -- no workgroup barrier at all.
-__global__ __launch_bounds__(256) void k_chroma_dc_waves(Geo g, FrameSel fs, DevBufs b)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char s_dyn[];       // [4 waves][nmb rounded up to 8, + 8] block sums in, predictors out
-    __shared__ int s_rec[4][2][512];
-    __shared__ int16_t s_dummy[4];
-    __shared__ int s_dummy32[4];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), l = lane_id();
-    const int pair = (int)blockIdx.x * 4 + wave;
-    if (pair >= 2 * fs.count) return;
-    const int slot = fs_slot(fs, pair >> 1), pl = pair & 1;
-    const int cols = g.sw, rows = g.sh, nblk = g.nmb;
-    int16_t* s_sp = (int16_t*)s_dyn + wave * (((nblk + 7) & ~7) + 8);
-    const long long fb = (long long)slot * g.nmb;
-    const uint8_t* plane = b.frames + slot * g.fsz + (long long)g.W * g.H + (long long)pl * g.cw * g.ch;
-    const int i = l & 7, jb = l >> 3;
-    for (int n0 = 0; n0 < nblk; n0 += 32) {
-        int nn[4]; uint2 row[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            nn[k] = min(n0 + 8 * k + jb, nblk - 1);
-            const int R = (int)__umulhi((unsigned)nn[k], g.msw), C = nn[k] - R * cols;       // n / sw, n % sw (Geo::msw)
-            row[k] = *(const uint2*)(plane + (uint32_t)(__mul24(R * 8 + i, g.cw) + C * 8));
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int v = (int)__builtin_amdgcn_sad_u8(row[k].y, 0, __builtin_amdgcn_sad_u8(row[k].x, 0, 0));
-            v += dpp<0xB1>(v); v += dpp<0x4E>(v); v += dpp<0x141>(v);      // sum over the 8 rows of the block
-            if (i == 0) s_sp[nn[k]] = (int16_t)v;
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // (one wave: its LDS accesses complete in order)
-    __builtin_amdgcn_wave_barrier();
-    if (rows <= 64) dc_chain_rows64<false>(s_sp, &s_dummy[wave], cols, rows, g.qdc, g.mdc, l);
-    else            dc_chain_banded<false>(s_sp, &s_dummy[wave], &s_dummy32[wave], &s_rec[wave][0][0], cols, rows, g.qdc, g.mdc, l);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    for (int n = l; n < nblk; n += 64) b.dcpred[(fb + n) * 6 + 4 + pl] = s_sp[n];
-}
-
 #include "icsp_blk8.hip.inc"
 #include "icsp_pack.hip.inc"
 #include "icsp_dec.hip.inc"
@@ -471,13 +429,6 @@ int intra_luma32(const Geo& g, const FrameSel& fs, const DevBufs& b, int nw, hip
 
 void chroma_dc(const Geo& g, const FrameSel& fs, const DevBufs& b, hipStream_t st)
 {
-    // ICSP_CHROMA_DC_WAVES=1 (experiment): a chain per wave instead of a chain per workgroup
-    static const bool waves = [] { const char* v = getenv("ICSP_CHROMA_DC_WAVES"); return v && atoi(v) == 1; }();
-    const size_t lds = 4 * (size_t)(((g.nmb + 7) & ~7) + 8) * sizeof(int16_t);
-    if (waves && lds <= 64 * 1024) {
-        hipLaunchKernelGGL(k_chroma_dc_waves, dim3((2 * fs.count + 3) / 4), dim3(256), lds, st, g, fs, b);
-        return;
-    }
     hipLaunchKernelGGL(k_chroma_dc, dim3(fs.count, 2), dim3(256), (size_t)g.nmb * 2, st, g, fs, b);
 }
 

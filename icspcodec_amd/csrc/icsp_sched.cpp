@@ -1580,6 +1580,25 @@ static int pack_check(icsp_ctx* ctx, int first, int n)
     return (first % L != 0) ? ICSP_ERR_RANGE : ICSP_OK;
 }
 
+// lengths + scans of slots [first, first + n) on stream kst, the total read back: returns when the host has it.  No ordering against
+// the context's other streams here: the caller has made sure the range's encode is complete or queued in front of kst.
+static int pack_count_on(icsp_ctx* ctx, int first, int n, hipStream_t kst, unsigned long long* total_out)
+{
+    if (int rc = pack_alloc(ctx)) return rc;
+    const Geo& g = ctx->g;
+    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
+    const int nchunk = pack_chunks(pack_groups(g, n));
+    const DevBufs& b = ctx->b;
+    const PackBufs& pk = ctx->pk;
+    LT(ctx, ICSP_K_PACK, kst, [&] { bits_count_scan(g, first, n, L, b, pk, kst); });
+    unsigned long long* total = (unsigned long long*)ctx->pk_host;
+    HIPCHK(hipMemcpyAsync(total, pk.chunk_base + nchunk, 8, hipMemcpyDeviceToHost, kst));
+    HIPCHK(hipStreamSynchronize(kst));
+    if (int rc = pack_reserve(ctx, *total)) return rc;
+    *total_out = *total;
+    return ICSP_OK;
+}
+
 int icsp_pack_count(icsp_ctx_t* ctx, int first, int n, uint64_t* nbits)
 {
     ENTER(ctx);
@@ -1590,32 +1609,62 @@ int icsp_pack_count(icsp_ctx_t* ctx, int first, int n, uint64_t* nbits)
     if (n == 0) { ctx->pk_first = first; ctx->pk_n = 0; ctx->pk_total = 0; return ICSP_OK; }
     HIPCHK(hipSetDevice(ctx->device));
     if (int rc = join_all(ctx)) return rc;
-    if (int rc = pack_alloc(ctx)) return rc;
-    const Geo& g = ctx->g;
-    const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
-    hipStream_t st = ctx->stream;
-    const int nchunk = pack_chunks(pack_groups(g, n));
-    const DevBufs& b = ctx->b;
-    const PackBufs& pk = ctx->pk;
-    LT(ctx, ICSP_K_PACK, st, [&] { bits_count_scan(g, first, n, L, b, pk, st); });
-    unsigned long long* total = (unsigned long long*)ctx->pk_host;
-    HIPCHK(hipMemcpyAsync(total, pk.chunk_base + nchunk, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (int rc = pack_reserve(ctx, *total)) return rc;
-    ctx->pk_first = first; ctx->pk_n = n; ctx->pk_total = *total;
-    *nbits = *total;
+    unsigned long long total = 0;
+    if (int rc = pack_count_on(ctx, first, n, ctx->stream, &total)) return rc;
+    ctx->pk_first = first; ctx->pk_n = n; ctx->pk_total = total;
+    *nbits = total;
     return ICSP_OK;
 }
 
 // the packing kernels for the range icsp_pack_count last measured, the string starting at bit `sh` (0..7) of pk.out
-static int pack_write(icsp_ctx* ctx, int first, int n, unsigned sh)
+static int pack_write(icsp_ctx* ctx, int first, int n, unsigned sh, hipStream_t st = nullptr)
 {
     const Geo& g = ctx->g;
     const int L = ctx->p.intra_period > 0 ? ctx->p.intra_period : 1;
-    hipStream_t st = ctx->stream;
+    if (!st) st = ctx->stream;
     const DevBufs& b = ctx->b;
     const PackBufs& pk = ctx->pk;
     LT(ctx, ICSP_K_PACK, st, [&] { bits_pack(g, first, n, L, b, pk, sh, st); });
+    return ICSP_OK;
+}
+
+// A string of `total` bits (what pack_count_on last measured) goes to body_image + at_bit / 8 in two steps.
+// It is packed at the byte phase (mod 64) and bit phase it has in the image, so that device byte j and its place in the image are
+// congruent mod 64 and the bulk goes as one aligned copy (DMA engines crawl on odd addresses: 6 GB/s instead of 57 measured).  The
+// ragged head and tail (< 64 bytes each) come back through a pinned scratch; their outermost bytes may be shared with the
+// neighbouring strings and are OR-ed in, the rest is stored.
+static int pack_place_kernels(icsp_ctx* ctx, int first, int n, uint64_t at_bit, const uint8_t* body_image, hipStream_t kst)
+{
+    const size_t A = (size_t)((uintptr_t)(body_image + (size_t)(at_bit >> 3)) & 63);
+    return pack_write(ctx, first, n, (unsigned)(A * 8 + (unsigned)(at_bit & 7)), kst);
+}
+// the copies, on stream ds (ordered after the packing kernels by the caller); returns when the bytes are in the image
+static int pack_place_copy(icsp_ctx* ctx, unsigned long long total, uint64_t at_bit, uint8_t* body_image, hipStream_t ds)
+{
+    const unsigned sh = (unsigned)(at_bit & 7);
+    const size_t nb = (size_t)((sh + total + 7) / 8), b0 = (size_t)(at_bit >> 3);
+    uint8_t* dst = body_image + b0;
+    const size_t A = (size_t)((uintptr_t)dst & 63);
+    const uint8_t* out = (const uint8_t*)ctx->pk.out;              // device byte A + j  <->  dst[j]
+    const size_t lo = A, hi = A + nb;
+    size_t ilo = (lo + 1 + 63) & ~(size_t)63, ihi = (hi - 1) & ~(size_t)63;      // aligned interior, first and last byte excluded
+    if (ihi <= ilo) ilo = ihi = hi;                                // short string: everything through the scratch
+    const size_t nhead = std::min(ilo, hi) - lo, ntail = hi - std::max(ihi, lo + nhead);
+    uint8_t* head = ctx->pk_host + 64;
+    uint8_t* tail = ctx->pk_host + 192;                           // (head: up to 127 bytes when there is no interior)
+    if (ihi > ilo) { if (int rc = xfer_down(ctx, dst + (ilo - lo), out + ilo, ihi - ilo, ds)) return rc; }    // (an image in plain memory: staged)
+    if (nhead) HIPCHK(hipMemcpyAsync(head, out + lo, nhead, hipMemcpyDeviceToHost, ds));
+    if (ntail) HIPCHK(hipMemcpyAsync(tail, out + hi - ntail, ntail, hipMemcpyDeviceToHost, ds));
+    HIPCHK(hipStreamSynchronize(ds));
+    for (size_t j = 0; j < nhead; j++) {
+        if (j == 0 || j == nb - 1) __atomic_fetch_or(&dst[j], head[j], __ATOMIC_RELAXED);
+        else dst[j] = head[j];
+    }
+    for (size_t j = 0; j < ntail; j++) {
+        const size_t d = nb - ntail + j;
+        if (d == nb - 1) __atomic_fetch_or(&dst[d], tail[j], __ATOMIC_RELAXED);
+        else dst[d] = tail[j];
+    }
     return ICSP_OK;
 }
 
@@ -1630,36 +1679,10 @@ int icsp_pack_into(icsp_ctx_t* ctx, int first, int n, uint64_t at_bit, uint8_t* 
     const size_t nb = (size_t)((sh + ctx->pk_total + 7) / 8), b0 = (size_t)(at_bit >> 3);
     if (b0 + nb > cap || b0 + nb < b0) return ICSP_ERR_RANGE;
     HIPCHK(hipSetDevice(ctx->device));
-    // The string is packed at the byte phase (mod 64) and bit phase it has in the image, so that device byte j and its place
-    // in the image are congruent mod 64 and the bulk goes as one aligned copy (DMA engines crawl on odd addresses: 6 GB/s
-    // instead of 57 measured).  The ragged head and tail (< 64 bytes each) come back through a pinned scratch; their
-    // outermost bytes may be shared with the neighbouring strings and are OR-ed in, the rest is stored.
-    uint8_t* dst = body_image + b0;
-    const size_t A = (size_t)((uintptr_t)dst & 63);
-    if (int rc = pack_write(ctx, first, n, (unsigned)(A * 8 + sh))) return rc;
+    if (int rc = pack_place_kernels(ctx, first, n, at_bit, body_image, ctx->stream)) return rc;
     DownTurn turn;
-    if (int rc = copy_down_begin(ctx, turn)) return rc;
-    hipStream_t st = down_of(ctx);
-    const uint8_t* out = (const uint8_t*)ctx->pk.out;              // device byte A + j  <->  dst[j]
-    const size_t lo = A, hi = A + nb;
-    size_t ilo = (lo + 1 + 63) & ~(size_t)63, ihi = (hi - 1) & ~(size_t)63;      // aligned interior, first and last byte excluded
-    if (ihi <= ilo) ilo = ihi = hi;                                // short string: everything through the scratch
-    const size_t nhead = std::min(ilo, hi) - lo, ntail = hi - std::max(ihi, lo + nhead);
-    uint8_t* head = ctx->pk_host + 64;
-    uint8_t* tail = ctx->pk_host + 192;                           // (head: up to 127 bytes when there is no interior)
-    if (ihi > ilo) { if (int rc = xfer_down(ctx, dst + (ilo - lo), out + ilo, ihi - ilo, st)) return rc; }    // (an image in plain memory: staged)
-    if (nhead) HIPCHK(hipMemcpyAsync(head, out + lo, nhead, hipMemcpyDeviceToHost, st));
-    if (ntail) HIPCHK(hipMemcpyAsync(tail, out + hi - ntail, ntail, hipMemcpyDeviceToHost, st));
-    if (int rc = copy_down_end(ctx)) return rc;
-    for (size_t j = 0; j < nhead; j++) {
-        if (j == 0 || j == nb - 1) __atomic_fetch_or(&dst[j], head[j], __ATOMIC_RELAXED);
-        else dst[j] = head[j];
-    }
-    for (size_t j = 0; j < ntail; j++) {
-        const size_t d = nb - ntail + j;
-        if (d == nb - 1) __atomic_fetch_or(&dst[d], tail[j], __ATOMIC_RELAXED);
-        else dst[d] = tail[j];
-    }
+    if (int rc = copy_down_begin(ctx, turn)) return rc;             // (shared download stream: waits for the kernels, takes the device's turn)
+    if (int rc = pack_place_copy(ctx, ctx->pk_total, at_bit, body_image, down_of(ctx))) return rc;
     if (ctx->profiling) collect_profile(ctx);
     return ICSP_OK;
 }
@@ -1782,7 +1805,18 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
     cf = std::max<long long>(L, (cf + L - 1) / L * L);
     if (cf > n) cf = n;
     std::vector<int> c_first, c_n;
-    {
+    // Only the bits come back (body, no levels): nothing big goes down, the call is as long as its uploads plus whatever the LAST chunk
+    // still needs when it has arrived (its kernels, its packing, its bits) -- so the chunks get SMALLER, each about 0.6 of the one before,
+    // down to a sixteenth of the frames, and every chunk's bits are packed and fetched while the next one is encoded (below).
+    const bool tail_bound = body && !levels;
+    if (tail_bound) {
+        const long long last = std::max<long long>(L, ((n + 15) / 16 + L - 1) / L * L);
+        std::vector<long long> sz{ last };
+        long long sum = last;
+        while (sum < n) { long long k = std::max<long long>(L, (sz.back() * 5 / 3 + L - 1) / L * L); k = std::min(k, (long long)n - sum); sz.push_back(k); sum += k; }
+        long long f = 0;
+        for (size_t k = sz.size(); k-- > 0; ) { c_first.push_back((int)f); c_n.push_back((int)sz[k]); f += sz[k]; }
+    } else {
         long long sz = std::max<long long>(L, ((n + 15) / 16 + L - 1) / L * L);
         for (long long f = 0; f < n; ) {
             const long long k = std::min<long long>(std::min(sz, cf), n - f);
@@ -1849,6 +1883,8 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
 
     // ---- this thread: encode chunk c, then bring chunk c-1 down while c runs; the staged results of c-2 leave meanwhile
     int rc = 0;
+    uint64_t at_bit = 0;                                           // body: bits placed so far
+    if (body) { if ((rc = pack_alloc(ctx))) return rc; ctx->pk_first = -1; }
     auto stage_off_recon = [&](size_t cn) { return (levels && !lv_direct) ? cn * lvf : (size_t)0; };
     auto unstage = [&](int c) {                                                    // staging buffer -> the caller's arrays
         const size_t f0 = (size_t)c_first[c], cn = (size_t)c_n[c];
@@ -1891,6 +1927,21 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
                 if (e == hipSuccess && d >= 1 && need_out) unstage(d - 1);        // (the other staging buffer, beside the transfer)
                 if (e == hipSuccess) e = hipStreamSynchronize(ds);
                 if (e != hipSuccess) { (void)hipGetLastError(); rc = ICSP_ERR_HIP; ctx->err = std::string("icsp_encode_gop download: ") + hipGetErrorString(e); break; }
+                if (body) {
+                    // chunk d's bits, on the download stream (its encode is complete: the events above; chunk d + 1 is being encoded on the
+                    // context's own streams meanwhile): count, pack at the bit the body has reached, fetch
+                    unsigned long long bits_d = 0;
+                    if ((rc = pack_count_on(ctx, (int)f0, (int)cn, ds, &bits_d))) break;
+                    const size_t b0 = (size_t)(at_bit >> 3), nbd = (size_t)(((at_bit & 7) + bits_d + 7) / 8);
+                    if (b0 + nbd > body_cap) { rc = ICSP_ERR_RANGE; break; }
+                    if (bits_d) {
+                        if ((at_bit & 7) == 0) body[b0] = 0;                      // the outermost bytes of a string are OR-ed into the image
+                        if (nbd > 1 || (at_bit & 7) == 0) body[b0 + nbd - 1] = 0;
+                        if ((rc = pack_place_kernels(ctx, (int)f0, (int)cn, at_bit, body, ds))) break;
+                        if ((rc = pack_place_copy(ctx, bits_d, at_bit, body, ds))) break;
+                        at_bit += bits_d;
+                    }
+                }
             }
         }
     }
@@ -1912,15 +1963,7 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
     if (int r2 = fetch(acflag, ctx->b.acflag, nmb6 * 6)) return r2;
     if (int r2 = fetch(mpm, ctx->b.mpm, nmb6 * 4)) return r2;
     if (int r2 = fetch(mvd, ctx->b.mvd, nmb6 * 2)) return r2;
-    if (body) {
-        if (int r2 = icsp_pack_count(ctx, 0, n, nbits)) return r2;
-        const size_t nbytes = (size_t)((*nbits + 7) / 8);
-        if (nbytes > body_cap) { *nbits = 0; return ICSP_ERR_RANGE; }
-        if (nbytes) {
-            if (int r2 = pack_write(ctx, 0, n, 0)) return r2;
-            if (int r2 = fetch(body, ctx->pk.out, nbytes)) return r2;
-        }
-    }
+    if (body) *nbits = at_bit;                                      // (every chunk's bits were packed and fetched behind its encode)
     if (ctx->profiling) collect_profile(ctx);
     return ICSP_OK;
 }
