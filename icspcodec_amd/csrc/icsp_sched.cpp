@@ -40,6 +40,7 @@ namespace {
 struct EvPair { hipEvent_t a, b; int kernel; int sid; };
 constexpr int kMaxPGroups = 3;
 constexpr int kMaxFlights = 4;
+constexpr int kGopEvSets = 4;          // sets of per-stream events of icsp_encode_gop's chunks (a power of two)
 // A range of frame slots whose encode may still be running on the context's streams and has not been joined onto `stream`.
 // Two encodes need no ordering between them when their ranges are disjoint (closed GOPs / independent frames: the reference's
 // GOP jobs, ENC:186-213) or identical (the same partition onto the same streams: stream order does it); anything else
@@ -109,7 +110,7 @@ struct icsp_ctx {
     uint8_t* gop_stage_in[2];
     uint8_t* gop_stage_out[2];
     size_t gop_stage_in_cap, gop_stage_out_cap;
-    hipEvent_t gop_ev[2][2 + 3];          // per chunk in flight (two): one event per stream of the context (stream, stream2, group streams)
+    hipEvent_t gop_ev[kGopEvSets][2 + 3]; // per chunk in flight (two; four when every chunk is queued on arrival): one event per stream of the context (stream, stream2, group streams)
     struct CopyPool* gop_pool;
     // every transfer from or into caller memory that is not KNOWN to be pinned goes through those staging buffers (xfer_up /
     // xfer_down): the runtime never sees a plain caller pointer.  xfer_ev_*: the DMA that last used a staging buffer
@@ -894,9 +895,9 @@ void gop_release(icsp_ctx* ctx)
         ctx->xfer_ev_in[k] = ctx->xfer_ev_out[k] = nullptr; ctx->xfer_in_busy[k] = false;
         if (ctx->gop_stage_in[k]) (void)hipHostFree(ctx->gop_stage_in[k]);
         if (ctx->gop_stage_out[k]) (void)hipHostFree(ctx->gop_stage_out[k]);
-        for (auto& e : ctx->gop_ev[k]) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         ctx->gop_stage_in[k] = ctx->gop_stage_out[k] = nullptr;
     }
+    for (auto& set : ctx->gop_ev) for (auto& e : set) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     ctx->gop_stage_in_cap = ctx->gop_stage_out_cap = 0;
 }
 
@@ -1805,17 +1806,24 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
     cf = std::max<long long>(L, (cf + L - 1) / L * L);
     if (cf > n) cf = n;
     std::vector<int> c_first, c_n;
-    // Only the bits come back (body, no levels): nothing big goes down, the call is as long as its uploads plus whatever the LAST chunk
-    // still needs when it has arrived (its kernels, its packing, its bits) -- so the chunks get SMALLER, each about 0.6 of the one before,
-    // down to a sixteenth of the frames, and every chunk's bits are packed and fetched while the next one is encoded (below).
-    const bool tail_bound = body && !levels;
+    // Only the bits come back (body, no levels, no reconstruction): nothing big goes down, and the call is as long as its uploads plus whatever the LAST
+    // chunk still needs once it has arrived (its kernels -- an I-frame launch takes 0.2 ms whatever its size --, its packing, its bits).
+    // So: few chunks, the last one a quarter of the frames (at most a quarter of the largest chunk), the others equal; every chunk's bits
+    // are packed and fetched behind its own encode while the next chunk's kernels run (below).  300 CIF frames: 225 + 75.
+    const bool tail_bound = body && !levels && !recon;              // (with the reconstruction to bring down the downloads set the pace: doubling chunks, below)
     if (tail_bound) {
-        const long long last = std::max<long long>(L, ((n + 15) / 16 + L - 1) / L * L);
-        std::vector<long long> sz{ last };
-        long long sum = last;
-        while (sum < n) { long long k = std::max<long long>(L, (sz.back() * 5 / 3 + L - 1) / L * L); k = std::min(k, (long long)n - sum); sz.push_back(k); sum += k; }
+        // halves: 1/2, 1/4, ... of what is left, down to about a sixth of the largest chunk (300 CIF frames: 150 + 75 + 75 -> 150, 100, 50)
+        const long long gops = (n + L - 1) / L;
+        std::vector<long long> g;                                   // chunk sizes in GOPs
+        long long left = gops;
+        const long long cap = std::max<long long>(1, cf / L);
+        while (left > 0) {
+            long long k = std::min<long long>(cap, std::max<long long>(1, (left + 1) / 2));
+            if (g.size() >= 2 || left <= std::max<long long>(1, gops / 6)) k = std::min(left, cap);      // the third chunk takes the rest
+            g.push_back(k); left -= k;
+        }
         long long f = 0;
-        for (size_t k = sz.size(); k-- > 0; ) { c_first.push_back((int)f); c_n.push_back((int)sz[k]); f += sz[k]; }
+        for (long long k : g) { const long long fr = std::min<long long>(k * L, n - f); c_first.push_back((int)f); c_n.push_back((int)fr); f += fr; }
     } else {
         long long sz = std::max<long long>(L, ((n + 15) / 16 + L - 1) / L * L);
         for (long long f = 0; f < n; ) {
@@ -1841,7 +1849,7 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
     if (!ctx->up_stream) { if (int rc = icsp_copy_streams(ctx, 1)) return rc; }          // (once per device and process: two DMA engines)
     if (int rc = join_all(ctx)) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));                    // whatever still reads the frame store or writes the results
-    for (int k = 0; k < 2; k++) for (auto& e : ctx->gop_ev[k]) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (int k = 0; k < kGopEvSets; k++) for (auto& e : ctx->gop_ev[k]) if (!e) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     const bool in_direct = host_pinned(yuv, (size_t)n * fsz);
     const bool lv_direct = host_pinned(levels, (size_t)n * lvf), rc_direct = host_pinned(recon, (size_t)n * fsz);
     const size_t need_in = in_direct ? 0 : (size_t)cf * fsz;
@@ -1852,6 +1860,14 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
     if (need_out) { if (int rc = stage_reserve(ctx, false, need_out)) return rc; }
     if ((need_in || need_out) && !copy_pool(ctx->gop_pool)) return ICSP_ERR_MEM_ALLOC;
 
+    // ICSP_TRACE_GOP=1 (diagnostics): when every phase of every chunk ended, in microseconds from here, on stderr
+    static const bool trace_gop = getenv("ICSP_TRACE_GOP") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto tr = [&](const char* what, int c) {
+        if (trace_gop) fprintf(stderr, "[gop] %8.1f us  %-14s chunk %d (%d frames)\n",
+                               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_call).count(), what, c, c < nc ? c_n[c] : 0);
+    };
+    tr("set-up done", 0);
     // ---- uploader thread: chunk after chunk onto the device's upload stream (one transfer at a time per stream: copy_up's rule)
     std::mutex um; std::condition_variable ucv;
     int uploaded = 0, up_rc = 0;
@@ -1876,6 +1892,7 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
             if (!ok) { (void)hipGetLastError(); up_rc = ICSP_ERR_HIP; ucv.notify_all(); break; }
             uploaded = c + 1;
             ucv.notify_all();
+            tr("uploaded", c);
         }
         delete pool;
     });
@@ -1892,31 +1909,72 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
         if (levels && !lv_direct) ctx->gop_pool->copy((char*)levels + f0 * lvf, st, cn * lvf);
         if (recon && !rc_direct) ctx->gop_pool->copy(recon + f0 * fsz, st + stage_off_recon(cn), cn * fsz);
     };
+    // Bits only: a third thread queues every chunk's kernels the moment the chunk has arrived, so that this one can sit in the packing
+    // and fetching of the chunk before (its host waits were what delayed the next encode: gpurun trace, profiles/r06_gop_trace.txt).  The
+    // two threads touch disjoint parts of the context (flight records and streams there; packer buffers and the download stream here);
+    // with per-kernel timing on they would share its event lists, so then the chunks are queued from this thread as below.
+    const bool use_launcher = tail_bound && nc > 1 && !ctx->profiling;
+    int queued = 0, q_rc = 0, packed_upto = -1;
+    auto queue_chunk = [&](int c) -> int {
+        const size_t f0 = (size_t)c_first[c], cn = (size_t)c_n[c];
+        if (int r = encode_range(ctx, (int)f0, (int)cn)) return r;
+        tr("encode queued", c);
+        hipStream_t sts[5] = { ctx->stream, ctx->stream2, ctx->pstream[0], ctx->pstream[1], ctx->pstream[2] };
+        for (int k = 0; k < 5; k++)
+            if (sts[k] && (k < 2 || sts[k] != ctx->stream) && hipEventRecord(ctx->gop_ev[c & (kGopEvSets - 1)][k], sts[k]) != hipSuccess) return poison(ctx, "hipEventRecord", hipGetLastError());
+        return 0;
+    };
+    std::thread launcher;
+    if (use_launcher) launcher = std::thread([&] {
+        if (hipSetDevice(ctx->device) != hipSuccess) { (void)hipGetLastError(); std::lock_guard<std::mutex> l(um); q_rc = ICSP_ERR_HIP; ucv.notify_all(); return; }
+        for (int c = 0; c < nc && !cancel.load(); c++) {
+            {
+                std::unique_lock<std::mutex> l(um);
+                ucv.wait(l, [&] { return uploaded > c || up_rc || cancel.load(); });
+                if (up_rc || cancel.load()) return;
+            }
+            // (chunk c's set of events is free once chunk c - kGopEvSets has been packed)
+            {
+                std::unique_lock<std::mutex> l(um);
+                ucv.wait(l, [&] { return packed_upto >= c - kGopEvSets || cancel.load(); });
+                if (cancel.load()) return;
+            }
+            const int r = queue_chunk(c);
+            std::lock_guard<std::mutex> l(um);
+            if (r) { q_rc = r; ucv.notify_all(); return; }
+            queued = c + 1;
+            ucv.notify_all();
+        }
+    });
+    struct Joiner2 { std::thread& t; std::atomic<bool>& c; std::condition_variable& cv; ~Joiner2() { c.store(true); cv.notify_all(); if (t.joinable()) t.join(); } } joiner2{ launcher, cancel, ucv };
     for (int c = 0; c <= nc && !rc; c++) {
-        if (c < nc) {
+        if (c < nc && use_launcher) {
+            // (queued by the launcher thread; this loop only follows it: chunk c - 1 is handled below once chunk c - 1 is queued)
+        } else if (c < nc) {
             {
                 std::unique_lock<std::mutex> l(um);
                 ucv.wait(l, [&] { return uploaded > c || up_rc; });
                 if (up_rc) { rc = up_rc; ctx->err = "icsp_encode_gop: upload failed"; break; }
             }
-            const size_t f0 = (size_t)c_first[c], cn = (size_t)c_n[c];
-            if ((rc = encode_range(ctx, (int)f0, (int)cn))) break;
             // "chunk c is through": an event behind what each stream of the context carries now -- everything of chunk c, nothing
             // of chunk c + 1 -- instead of a join, so that the chunks' kernels overlap the way encode_range lets disjoint ranges
-            hipStream_t sts[5] = { ctx->stream, ctx->stream2, ctx->pstream[0], ctx->pstream[1], ctx->pstream[2] };
-            for (int k = 0; k < 5 && !rc; k++)
-                if (sts[k] && (k < 2 || sts[k] != ctx->stream) && hipEventRecord(ctx->gop_ev[c & 1][k], sts[k]) != hipSuccess) rc = poison(ctx, "hipEventRecord", hipGetLastError());
-            if (rc) break;
+            if ((rc = queue_chunk(c))) break;
         }
         if (c >= 1) {
             const int d = c - 1;
             const size_t f0 = (size_t)c_first[d], cn = (size_t)c_n[d];
+            if (use_launcher) {
+                std::unique_lock<std::mutex> l(um);
+                ucv.wait(l, [&] { return queued > d || q_rc || up_rc; });
+                if (q_rc || up_rc) { rc = q_rc ? q_rc : up_rc; if (up_rc) ctx->err = "icsp_encode_gop: upload failed"; break; }
+            }
             {
                 hipStream_t sts[5] = { ctx->stream, ctx->stream2, ctx->pstream[0], ctx->pstream[1], ctx->pstream[2] };
                 for (int k = 0; k < 5 && !rc; k++)     // (an event never recorded counts as complete; a stream created since then carries later chunks only)
-                    if (sts[k] && hipEventSynchronize(ctx->gop_ev[d & 1][k]) != hipSuccess) { rc = ICSP_ERR_HIP; ctx->err = "hipEventSynchronize"; (void)hipGetLastError(); }
+                    if (sts[k] && hipEventSynchronize(ctx->gop_ev[d & (kGopEvSets - 1)][k]) != hipSuccess) { rc = ICSP_ERR_HIP; ctx->err = "hipEventSynchronize"; (void)hipGetLastError(); }
                 if (rc) break;
             }
+            tr("kernels done", d);
             {
                 std::lock_guard<std::mutex> t(g_down_turn[ctx->slot & 63]);
                 hipStream_t ds = ctx->down_stream;
@@ -1926,12 +1984,14 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
                 if (e == hipSuccess && recon) e = hipMemcpyAsync(rc_direct ? recon + f0 * fsz : st + stage_off_recon(cn), ctx->b.recon + f0 * fsz, cn * fsz, hipMemcpyDeviceToHost, ds);
                 if (e == hipSuccess && d >= 1 && need_out) unstage(d - 1);        // (the other staging buffer, beside the transfer)
                 if (e == hipSuccess) e = hipStreamSynchronize(ds);
+                tr("results down", d);
                 if (e != hipSuccess) { (void)hipGetLastError(); rc = ICSP_ERR_HIP; ctx->err = std::string("icsp_encode_gop download: ") + hipGetErrorString(e); break; }
-                if (body) {
+                if (tail_bound) {
                     // chunk d's bits, on the download stream (its encode is complete: the events above; chunk d + 1 is being encoded on the
                     // context's own streams meanwhile): count, pack at the bit the body has reached, fetch
                     unsigned long long bits_d = 0;
                     if ((rc = pack_count_on(ctx, (int)f0, (int)cn, ds, &bits_d))) break;
+                    tr("bits counted", d);
                     const size_t b0 = (size_t)(at_bit >> 3), nbd = (size_t)(((at_bit & 7) + bits_d + 7) / 8);
                     if (b0 + nbd > body_cap) { rc = ICSP_ERR_RANGE; break; }
                     if (bits_d) {
@@ -1941,11 +2001,16 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
                         if ((rc = pack_place_copy(ctx, bits_d, at_bit, body, ds))) break;
                         at_bit += bits_d;
                     }
+                    tr("bits down", d);
+                    { std::lock_guard<std::mutex> l(um); packed_upto = d; }
+                    ucv.notify_all();
                 }
             }
         }
     }
     cancel.store(true);
+    ucv.notify_all();
+    if (launcher.joinable()) launcher.join();
     if (uploader.joinable()) uploader.join();
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     if (need_out) unstage(nc - 1);
@@ -1963,7 +2028,16 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
     if (int r2 = fetch(acflag, ctx->b.acflag, nmb6 * 6)) return r2;
     if (int r2 = fetch(mpm, ctx->b.mpm, nmb6 * 4)) return r2;
     if (int r2 = fetch(mvd, ctx->b.mvd, nmb6 * 2)) return r2;
-    if (body) *nbits = at_bit;                                      // (every chunk's bits were packed and fetched behind its encode)
+    if (tail_bound) *nbits = at_bit;                                // (every chunk's bits were packed and fetched behind its encode)
+    else if (body) {
+        if (int r2 = icsp_pack_count(ctx, 0, n, nbits)) return r2;
+        const size_t nbytes = (size_t)((*nbits + 7) / 8);
+        if (nbytes > body_cap) { *nbits = 0; return ICSP_ERR_RANGE; }
+        if (nbytes) {
+            if (int r2 = pack_write(ctx, 0, n, 0)) return r2;
+            if (int r2 = fetch(body, ctx->pk.out, nbytes)) return r2;
+        }
+    }
     if (ctx->profiling) collect_profile(ctx);
     return ICSP_OK;
 }
