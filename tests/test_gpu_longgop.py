@@ -58,6 +58,33 @@ def test_config5_1088p_period30_two_gops():
     _full_check(clip, w, h, 16, 30, "1088p p30: ")
 
 
+def test_config5_full_3000_frames_100_gops():
+    """BASELINE configs[4] at its FULL size: 3000 frames of 1920x1088 = 100 closed GOPs of 30 resident at once (40 GB
+    of HBM), one pass -- the batch bench.py's `config5` leg times.  GOP g shows content (g mod 4) (icspcodec_amd/workloads.py: the CIF
+    clips tiled over the frame): every one of the 100 GOPs must reproduce the oracle's levels-and-all result of its content, i.e. 25
+    GOPs per content, bit for bit in the reconstruction, and the first GOP of each content in every output array."""
+    from icspcodec_amd import workloads
+    w, h, L, ngop = workloads.HD_W, workloads.HD_H, workloads.HD_PERIOD, workloads.HD_GOPS
+    g_lo, g_n, gops = workloads.hd_shard(0, 1)
+    assert (g_lo, g_n) == (0, ngop)
+    srcs = workloads.HD_SRCS
+    allw = po.encode_sequence(np.concatenate([gops[nm] for nm in srcs]), w, h, 16, 16, L, nthreads=min(4, NT))     # one GOP per thread
+    want = {nm: {k: v[j * L: (j + 1) * L] for k, v in allw.items()} for j, nm in enumerate(srcs)}
+    enc = capi.Encoder(w, h, 16, 16, L, max_frames=ngop * L)
+    for g in range(ngop):
+        enc.upload(gops[srcs[g % 4]], first=g * L)
+    enc.encode_resident(0, ngop * L)
+    enc.sync()
+    for g in range(ngop):
+        nm = srcs[g % 4]
+        if g < 4:
+            _cmp(enc.download(g * L, L), want[nm], f"GOP {g} ({nm}): ")
+        else:
+            rec = enc.download(g * L, L, what=("recon",))["recon"]
+            assert np.array_equal(rec, want[nm]["recon"]), f"GOP {g} ({nm}): reconstruction differs from the oracle"
+    enc.close()
+
+
 def test_cif_period30_static_content():
     """29 consecutive flagged P steps per GOP (two GOPs + a ragged third)."""
     clip = _static_clip(67)
