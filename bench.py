@@ -617,7 +617,7 @@ def main():
     enc.close()
     fps = world * NFRAMES * a.steps / dt
     kern_ms = ms_ai / max(n_ai, 1)
-    # A step launches the luma kernel in `lps` parts on as many streams (more frames than CUs: icsp_device.hip, encode_range),
+    # A step launches the luma kernel in `lps` parts on as many streams (more frames than CUs: icsp_sched.cpp, encode_range),
     # and the launches of consecutive steps (independent batches) run side by side as well, so a launch's own duration says
     # little about the chip.  Chip-level figure: the kernel's algorithmic bytes of a step over the step's share of
     # the timed region -- in steady state the span of a step's launches -- i.e. bytes per step / ms_per_step.  The per-launch
