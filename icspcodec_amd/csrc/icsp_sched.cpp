@@ -1383,7 +1383,7 @@ namespace {
 // Transfers of a context that uses the device's shared transfer streams (icsp_copy_streams): uploads run on one stream,
 // downloads on another; a transfer starts when the context's own stream is idle and the host waits for it, one at a time per
 // stream and device.
-std::mutex g_up_turn[64];       // one upload at a time on a device's shared upload stream (see g_down_turn)
+static std::mutex g_up_turn[64];       // one upload at a time on a device's shared upload stream (see g_down_turn)
 static int copy_up(icsp_ctx* ctx, void* dst, const void* src, size_t bytes)
 {
     hipStream_t st = ctx->stream, up = ctx->up_stream;
@@ -1397,7 +1397,7 @@ static int copy_up(icsp_ctx* ctx, void* dst, const void* src, size_t bytes)
 // One download at a time on a device's shared download stream: a copy submitted while the stream's engine is busy is given
 // another engine -- possibly the upload stream's, if that one happens to be idle -- and from then on the two directions take
 // turns on it.  The turn is taken when the context's kernels are through, so that it covers the copies alone.
-std::mutex g_down_turn[64];
+static std::mutex g_down_turn[64];
 struct DownTurn { std::mutex* m = nullptr; ~DownTurn() { if (m) m->unlock(); } };
 static hipStream_t down_of(icsp_ctx* ctx) { return ctx->down_stream ? ctx->down_stream : ctx->stream; }
 static int copy_down_begin(icsp_ctx* ctx, DownTurn& turn)

@@ -44,6 +44,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)   /* the library itself is built with -fvisibility=hidden: these entry points are all it exports */
+#endif
 
 typedef enum {
     ICSP_OK = 0,                 /* SUCCESS          (ICSP_Codec_Encoder.h:35) */
@@ -285,6 +288,9 @@ int icsp_upload_syntax(icsp_ctx_t* ctx, int first_frame, int n, const int16_t* l
  * differs from the encoder's reconstruction by a grey level on a few pixels.  Asynchronous; fetch with icsp_download. */
 int icsp_decode_resident(icsp_ctx_t* ctx, int first_frame, int n);
 
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -24,6 +24,11 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert getattr(lib, s) is not None
     assert lib.icsp_strerror(0) == b"success"
     assert lib.icsp_kernel_name(0) == b"k_intra_luma"
+    # ... and nothing else: the launch layer between the two translation units (icsp_kernels.h) and the host helpers stay inside
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = {l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in ("T", "t")}
+    assert exported == declared, exported ^ declared
 
 
 def test_poisoned_context_keeps_returning_hip_error():
