@@ -77,6 +77,8 @@ struct icsp_ctx {
     bool p_dirty;
     Flight flight[kMaxFlights];
     int last_first, last_n, rr;       // the range of the previous encode call (alternation between ranges -> whole placement); stream turn
+    std::vector<std::pair<int, int>> last_list;   // ... its ranges when it was a list (last_first / last_n are then the list's hull): a plain range in a
+                                                  // hole of the hull is as independent of the list as one outside it
     int prev2_first, prev2_n;         // ... and of the call before it (three ranges in rotation -> three chain streams, all-intra)
     bool chains3;                     // ICSP_CHAINS3=0: two chain streams whatever the rotation (comparison)
     int last_form, last_nw, last_ring, last_whole, last_groups, last_rowgroup;     // what the last encode chose (icsp_debug_last_choice)
@@ -388,11 +390,16 @@ int launch_p_step(icsp_ctx* ctx, const DevBufs& b, const FrameSel& fs, hipStream
 // (0 = `stream`, 1, 2 = pstream[1], pstream[2]) a whole range takes.  The state moves on as a side effect.
 struct TurnState { int last_first, last_n, prev2_first, prev2_n, rr; };
 struct Turn { bool whole, three; int turn; };
-Turn plan_turn(TurnState& t, int first, int n, int L, bool may_whole, bool chains3)
+Turn plan_turn(TurnState& t, int first, int n, int L, bool may_whole, bool chains3, const std::vector<std::pair<int, int>>* last_list = nullptr)
 {
     auto apart = [](int a, int an, int b_, int bn) { return a >= b_ + bn || b_ >= a + an; };
     Turn r{ false, false, 0 };
-    r.whole = may_whole && t.last_n > 0 && apart(first, n, t.last_first, t.last_n);
+    bool apart_last = apart(first, n, t.last_first, t.last_n);
+    if (!apart_last && last_list && !last_list->empty()) {           // the previous call was a list: range by range, not its hull
+        apart_last = true;
+        for (auto& q : *last_list) apart_last = apart_last && apart(first, n, q.first, q.second);
+    }
+    r.whole = may_whole && t.last_n > 0 && apart_last;
     r.three = chains3 && r.whole && L == 1 && t.prev2_n > 0 && apart(first, n, t.prev2_first, t.prev2_n) &&
               apart(t.last_first, t.last_n, t.prev2_first, t.prev2_n);
     t.prev2_first = t.last_first; t.prev2_n = t.last_n;
@@ -434,7 +441,8 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     // 0.39 M, 720p 3 x 30: 58 -> 86 k, 1088p 3 x 15: 16 -> 24 k (profiles/r05_exp_chains3.txt).  Two ranges alternating stay as they were
     // (a range follows its own previous pass: two in flight is all there can be).
     TurnState ts{ ctx->last_first, ctx->last_n, ctx->prev2_first, ctx->prev2_n, ctx->rr };
-    const Turn turn = plan_turn(ts, first, n, L, !single && lazy && ctx->whole_ok, ctx->chains3);
+    const Turn turn = plan_turn(ts, first, n, L, !single && lazy && ctx->whole_ok, ctx->chains3, &ctx->last_list);
+    ctx->last_list.clear();
     const bool whole = turn.whole, three = turn.three;
     ctx->last_first = ts.last_first; ctx->last_n = ts.last_n; ctx->prev2_first = ts.prev2_first; ctx->prev2_n = ts.prev2_n; ctx->rr = ts.rr;
     int NG = ctx->p_groups;
@@ -637,6 +645,7 @@ int encode_many(icsp_ctx* ctx, int k, const int* firsts, const int* ns)
     hipStream_t st = ctx->stream, s2 = ctx->stream2;
     ctx->prev2_first = ctx->last_first; ctx->prev2_n = ctx->last_n;
     ctx->last_first = hull_first; ctx->last_n = hull_n; ctx->last_whole = 1; ctx->last_groups = 1;
+    ctx->last_list = rs;
     if (int rc = many_tables(ctx, L)) return rc;
     Flight* F = nullptr;
     bool same = false, joined = false;

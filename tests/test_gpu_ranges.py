@@ -299,6 +299,23 @@ def test_coalesced_ranges_match_per_range_calls(period, q, lens, gap):
     enc.close()
 
 
+def test_plain_range_in_a_hole_of_a_list_is_placed_whole():
+    """the placement rule looked at a list's HULL, so a plain range lying in a hole of the previous call's list was never
+    placed whole on one chain stream although it is as independent of the list as a range outside it.  (Results never depend on it.)"""
+    clip = np.concatenate([clipgen.synth_clip("foremanlike", 300), clipgen.synth_clip("mobilelike", 100)])
+    enc = capi.Encoder(W, H, 16, 16, 0, max_frames=400)
+    enc.upload(clip)
+    enc.encode_resident_many([(0, 100), (300, 100)])
+    enc.encode_resident(150, 100)                                     # in the hole [100, 300)
+    assert enc.last_choice()["range_whole_on_one_stream"]
+    enc.encode_resident_many([(0, 100), (300, 100)])
+    enc.encode_resident(50, 100)                                      # overlaps the list's first range: not independent
+    assert not enc.last_choice()["range_whole_on_one_stream"]
+    want = po.encode_sequence(clip[150:250], W, H, 16, 16, 1, nthreads=NT)
+    _cmp(enc.download(150, 100), want, "range in the hole: ")
+    enc.close()
+
+
 def test_coalesced_ranges_refuse_overlap_and_misalignment():
     enc = capi.Encoder(W, H, 16, 16, 10, max_frames=100)
     with pytest.raises(RuntimeError):
