@@ -448,7 +448,12 @@ int encode_range(icsp_ctx* ctx, int first, int n)
     int NG = ctx->p_groups;
     // keep every group's launches wide enough to be worth splitting: a dozen GOPs per group (tools/sweep_regimes.py, one CIF range
     // encoded again and again: 10 GOPs 0.358 M frames/s in one group against 0.341 M in two, 20 GOPs 0.679 / 0.656, 25 GOPs 0.762 / 0.812)
-    if (NG > G / 12) NG = G / 12;
+    // Frames of 2048 macroblocks and more run the serial kernel as a launch of its own (60 us at 1088p, the chip idle beside it): there
+    // three GOPs per group are enough -- 1088p, one range again and again, 6 GOPs 45.8 -> 49.1 k frames/s, 13 GOPs (a rank's share of
+    // configs[4] split eight ways) 62.8 -> 68.9 k, 25 GOPs and more two groups either way.  (Splitting 4CIF / 720p / 352x576 ranges
+    // earlier than a dozen GOPs per group loses 1-4 %: profiles/r06_ab_group_threshold.txt.)
+    const int min_gops = g.nmb >= 2048 ? 3 : 12;
+    if (NG > G / min_gops) NG = G / min_gops;
     if (NG < 1 || L == 1 || whole || single) NG = 1;
     auto group_lo = [&](int k) { return (int)((long long)G * k / NG); };
     // Which ranges are in flight decides the ordering against earlier calls (flight_admit): the same range again, or a range
