@@ -1928,6 +1928,12 @@ static int gop_pipeline(icsp_ctx* ctx, const uint8_t* yuv, int n, int16_t* level
     // two threads touch disjoint parts of the context (flight records and streams there; packer buffers and the download stream here);
     // with per-kernel timing on they would share its event lists, so then the chunks are queued from this thread as below.
     const bool use_launcher = tail_bound && nc > 1 && !ctx->profiling;
+    if (use_launcher && !ctx->single) {
+        // every stream an encode may want exists before the launcher starts: this thread reads the stream handles (the per-chunk
+        // events below) while that one runs encode_range, which would otherwise create them on first use
+        if ((rc = second_stream(ctx))) return rc;
+        if ((rc = group_streams(ctx, kMaxPGroups))) return rc;
+    }
     int queued = 0, q_rc = 0, packed_upto = -1;
     auto queue_chunk = [&](int c) -> int {
         const size_t f0 = (size_t)c_first[c], cn = (size_t)c_n[c];
